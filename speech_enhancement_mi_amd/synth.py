@@ -1,0 +1,186 @@
+"""Deterministic synthetic weights and audio for parity tests and benchmarks.
+
+No trained checkpoint and no dataset ship with the reference, so
+parity is defined on *identical* pseudo-random weights and synthetic 16 kHz
+multi-microphone audio.  Both generators are pure integer hashing (splitmix64
+finaliser) so that numpy here, the C oracle and any other host can regenerate
+bit-identical tensors without shipping megabytes of fixtures and without
+depending on a torch RNG stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+
+_M64 = (1 << 64) - 1
+_GOLD = 0x9E3779B97F4A7C15
+_C1 = 0xBF58476D1CE4E5B9
+_C2 = 0x94D049BB133111EB
+
+
+def fnv1a64(text: str) -> int:
+    h = 0xCBF29CE484222325
+    for ch in text.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & _M64
+    return h
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64, copy=True)
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(_C1)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(_C2)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_uniform(stream: int, n: int) -> np.ndarray:
+    """n float32 values, uniform in [-1, 1), fully determined by (stream, index)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        x = idx * np.uint64(_GOLD) + np.uint64(stream & _M64)
+        x = _mix(_mix(x) + np.uint64(stream & _M64))
+    u24 = (x >> np.uint64(40)).astype(np.float64)  # 24 random bits
+    return (u24 / float(1 << 23) - 1.0).astype(np.float32)
+
+
+def hash_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    stream = (fnv1a64(key) ^ ((seed * _C1) & _M64)) & _M64
+    return hash_uniform(stream, n).reshape(shape)
+
+
+def _fan_in(key: str, shape: Tuple[int, ...]) -> int:
+    if len(shape) <= 1:
+        return 1
+    if ".conv.weight" in key and key.startswith("deconvlist"):
+        # ConvTranspose2d weight is [Cin, Cout, kh, kw]; every output sums Cin * taps/stride inputs
+        return shape[0] * shape[2] * shape[3]
+    return int(np.prod(shape[1:]))
+
+
+def make_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0) -> Dict[str, np.ndarray]:
+    """Hash-generated weights for a list of (checkpoint key, shape).
+
+    Scales follow the spirit of PyTorch's default initialisers (U(-1/sqrt(fan_in), +)) so
+    activations stay O(1); norm affines are perturbed away from (1, 0) so that a missing or
+    mis-broadcast affine shows up in parity tests.
+    """
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in spec:
+        shape = tuple(int(s) for s in shape)
+        # the reference registers each conv twice (self.conv and self.net[0], CRN.py:314-316), so its
+        # state_dict carries `...net.0.weight` aliases of `...conv.weight`: both get the same tensor.
+        key = name.replace(".net.0.", ".conv.")
+        u = hash_tensor(key, shape, seed)
+        if ".norm." in key or "norm.weight" in key or "norm.bias" in key:
+            if key.endswith("weight"):
+                t = 1.0 + 0.25 * u
+            else:
+                t = 0.25 * u
+        elif key.endswith("bias"):
+            t = 0.1 * u
+        else:
+            t = u * (1.7 / math.sqrt(max(1, _fan_in(key, shape))))
+        out[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return out
+
+
+def crn_param_spec(num_channels, num_freqs, hidden, num_layers=1, num_inputs=3, kernel_size=3):
+    """(key, shape) list of reference TemporalCRN.state_dict() — CRN.py:428-451 (checked against
+    the live reference module by tests/golden/make_golden.py, fixture crn_keys.json)."""
+    spec = []
+    L = len(num_channels)
+    for i in range(L):
+        cin = (2 * num_inputs - 1) if i == 0 else num_channels[i - 1]
+        cout = num_channels[i]
+        p = f"convlist.{i}."
+        spec += [(p + "conv.weight", (cout, cin, 5, kernel_size)), (p + "conv.bias", (cout,)),
+                 (p + "net.0.weight", (cout, cin, 5, kernel_size)), (p + "net.0.bias", (cout,)),
+                 (p + "norm.weight", (1, cout, 1, 1)), (p + "norm.bias", (1, cout, 1, 1))]
+    for j in range(L):
+        i = L - 1 - j  # deconvlist[j] mirrors encoder level i (CRN.py:438-444)
+        cin = num_channels[i]
+        cout = 2 if i == 0 else num_channels[i - 1]
+        p = f"deconvlist.{j}."
+        spec += [(p + "conv.weight", (cin, cout, 5, kernel_size)), (p + "conv.bias", (cout,)),
+                 (p + "net.0.weight", (cin, cout, 5, kernel_size)), (p + "net.0.bias", (cout,)),
+                 (p + "residualmask.weight", (cout, cout, 1, 1)), (p + "residualmask.bias", (cout,)),
+                 (p + "residualnorm.weight", (1, cout, 1, 1)), (p + "residualnorm.bias", (1, cout, 1, 1)),
+                 (p + "residual.weight", (cout, cout, 1, 1)), (p + "residual.bias", (cout,)),
+                 (p + "norm.weight", (1, cout, 1, 1)), (p + "norm.bias", (1, cout, 1, 1))]
+    D = (num_freqs // 16 + 1) * num_channels[-1]
+    for l in range(num_layers):
+        ins = D if l == 0 else hidden
+        spec += [(f"gru.sequence_model.weight_ih_l{l}", (3 * hidden, ins)),
+                 (f"gru.sequence_model.weight_hh_l{l}", (3 * hidden, hidden)),
+                 (f"gru.sequence_model.bias_ih_l{l}", (3 * hidden,)),
+                 (f"gru.sequence_model.bias_hh_l{l}", (3 * hidden,))]
+    spec += [("gru.fc_output_layer.weight", (D, hidden)), ("gru.fc_output_layer.bias", (D,)),
+             ("gru.norm.weight", (1, 1, 1, D)), ("gru.norm.bias", (1, 1, 1, D))]
+    return spec
+
+
+def synth_utterances(batch: int, length: int, num_mics: int = 3, seed: int = 0,
+                     sample_rate: int = 16000):
+    """Synthetic noisy multi-mic speech-like audio: returns (mix [B,M,L], clean [B,L]).
+
+    Clean: 8 harmonics of f0~U[90,250] Hz under a 3-6 Hz raised-cosine syllabic envelope; noise:
+    one-pole low-passed white noise; each mic sees integer-lag/gain variants; SNR~U[-5,25] dB;
+    peak normalised to 0.95.  Stands in for data_c.py:210-252 + multichannel.py (gpuRIR).
+    """
+    mix = np.zeros((batch, num_mics, length), np.float32)
+    clean = np.zeros((batch, length), np.float32)
+    t = np.arange(length + 8, dtype=np.float64) / sample_rate
+    for b in range(batch):
+        u = hash_uniform(fnv1a64(f"utt{seed}:{b}"), 64).astype(np.float64) * 0.5 + 0.5  # U[0,1)
+        f0 = 90.0 + 160.0 * u[0]
+        env_f = 3.0 + 3.0 * u[1]
+        s = np.zeros_like(t)
+        for h in range(1, 9):
+            s += (1.0 / h) * np.sin(2 * np.pi * f0 * h * t + 2 * np.pi * u[1 + h])
+        env = 0.5 - 0.5 * np.cos(2 * np.pi * env_f * t + 2 * np.pi * u[10])
+        gate = (np.sin(2 * np.pi * (0.8 + u[11]) * t + 2 * np.pi * u[12]) > -0.6).astype(np.float64)
+        s = s * env * gate
+        w = hash_uniform(fnv1a64(f"noise{seed}:{b}"), length + 8).astype(np.float64)
+        n = np.empty_like(w)
+        acc = 0.0
+        # one-pole low-pass a=0.9 (vectorised via lfilter-equivalent recursion in blocks)
+        try:
+            from scipy.signal import lfilter
+            n = lfilter([1.0], [1.0, -0.9], w)
+        except Exception:  # pragma: no cover
+            for i in range(len(w)):
+                acc = 0.9 * acc + w[i]
+                n[i] = acc
+        snr_db = -5.0 + 30.0 * u[13]
+        ps = np.mean(s ** 2) + 1e-12
+        pn = np.mean(n ** 2) + 1e-12
+        n = n * math.sqrt(ps / (pn * 10 ** (snr_db / 10)))
+        mics = []
+        for m in range(num_mics):
+            ls = int(u[14 + 2 * m] * 7) % 7
+            ln = int(u[15 + 2 * m] * 7) % 7
+            gs = 0.7 + 0.3 * u[24 + 2 * m]
+            gn = 0.7 + 0.3 * u[25 + 2 * m]
+            mics.append(gs * s[ls:ls + length] + gn * n[ln:ln + length])
+        mics = np.stack(mics)
+        peak = np.max(np.abs(mics)) + 1e-12
+        scale = 0.95 / peak
+        mix[b] = (mics * scale).astype(np.float32)
+        clean[b] = (s[:length] * scale).astype(np.float32)
+    return mix, clean
+
+
+def si_sdr(reference: np.ndarray, estimation: np.ndarray) -> np.ndarray:
+    """Scale-invariant SDR in dB, the restatable eval metric (reference metrics.py:61-85)."""
+    estimation, reference = np.broadcast_arrays(estimation.astype(np.float64), reference.astype(np.float64))
+    ref_e = np.sum(reference ** 2, axis=-1, keepdims=True)
+    scale = np.sum(reference * estimation, axis=-1, keepdims=True) / ref_e
+    proj = scale * reference
+    noise = estimation - proj
+    return 10 * np.log10(np.sum(proj ** 2, axis=-1) / np.sum(noise ** 2, axis=-1))

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE GENUINE REFERENCE in this container.
+
+Run once, here (needs /root/reference; the GPU box never has it):
+
+    python tests/golden/make_golden.py
+
+What is pinned by the reference's own code, and what is not
+-----------------------------------------------------------
+* Everything inside ``TemporalCRN.forward`` (feature extraction, TemporalConv2d, GlobalLayerNorm,
+  SequenceModel/GRU, TemporalConvTranspose2d, decompress_cIRM, complex multiply), ``utility.segmentation``,
+  ``utility.over_add``, ``realtime_process`` orchestration, ``cal_si_snr`` and ``metrics.SI_SDR`` run from the
+  reference's source files unmodified.
+* The STFT/ISTFT arithmetic lives in speechbrain (un-vendored, unpinned, not installed).  The
+  two classes below named STFT/ISTFT restate speechbrain's thin wrapper over torch.stft/torch.istft so that the
+  reference files import; vectors that pass through them are therefore "parity unpinned at the speechbrain
+  boundary" - the de-facto oracle is torch.stft/istft of this container's torch.
+* torch_complex / torchaudio / speechbrain.utils stand-ins are empty import placeholders: nothing on the
+  CRN path touches them (only the unused MVDR beamformer and the STOI training loss do).
+
+Only DATA (inputs and outputs) is written to tests/golden/; no reference source text is copied.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SE_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True  # reference dir is read-only
+
+from speech_enhancement_mi_amd import synth  # noqa: E402
+
+
+def _install_import_placeholders():
+    tmp = tempfile.mkdtemp(prefix="se_shims_")
+    files = {
+        "torch_complex/__init__.py": "class ComplexTensor:  # placeholder, never used on the CRN path\n    pass\n",
+        "torch_complex/functional.py": "",
+        "torchaudio/__init__.py": "def set_audio_backend(name):\n    return None\n",
+        "torchaudio/transforms.py": "",
+        "speechbrain/__init__.py": "",
+        "speechbrain/utils/__init__.py": "",
+        "speechbrain/utils/torch_audio_backend.py": "def get_torchaudio_backend():\n    return 'soundfile'\n",
+        "speechbrain/processing/__init__.py": "",
+        "speechbrain/processing/features.py": textwrap.dedent('''
+            import torch
+            class STFT(torch.nn.Module):
+                """[batch, time] -> [batch, frames, freq, 2] (hamming, centre, constant pad)."""
+                def __init__(self, sample_rate, win_length=25, hop_length=10, n_fft=400):
+                    super().__init__()
+                    self.n_fft = n_fft
+                    self.win = int(round(sample_rate / 1000.0 * win_length))
+                    self.hop = int(round(sample_rate / 1000.0 * hop_length))
+                    self.window = torch.hamming_window(self.win)
+                def forward(self, x):
+                    s = torch.stft(x, self.n_fft, self.hop, self.win, self.window.to(x.device), center=True,
+                                   pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+                    return torch.view_as_real(s).transpose(2, 1)
+            class ISTFT(torch.nn.Module):
+                """[batch, frames, freq, 2] -> [batch, time]."""
+                def __init__(self, sample_rate, win_length=25, hop_length=10, n_fft=400):
+                    super().__init__()
+                    self.n_fft = n_fft
+                    self.win = int(round(sample_rate / 1000.0 * win_length))
+                    self.hop = int(round(sample_rate / 1000.0 * hop_length))
+                    self.window = torch.hamming_window(self.win)
+                def forward(self, x):
+                    x = torch.view_as_complex(x.transpose(2, 1).contiguous())
+                    return torch.istft(x, self.n_fft, self.hop, self.win, self.window.to(x.device), center=True,
+                                       normalized=False, onesided=True)
+        '''),
+    }
+    for rel, body in files.items():
+        path = os.path.join(tmp, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(body)
+    sys.path.insert(0, tmp)
+    sys.path.insert(1, REF)
+
+
+def load_reference():
+    _install_import_placeholders()
+    import CRN  # noqa
+    import utility  # noqa
+    return CRN, utility
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().astype(np.float32) if t.is_floating_point() else t.detach().cpu().numpy()
+
+
+def build_ref_model(CRN, cfg, seed=0):
+    model = CRN.TemporalCRN(**cfg)
+    spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd = synth.make_state_dict(spec, seed=seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    return model, spec, sd
+
+
+TINY = dict(num_channels=[4, 8, 8, 8], num_freqs=201, hidden=16, segment_length=3200, num_layers=2,
+            num_inputs=3, kernel_size=3, dropout=0.0, sample_rate=16000, win_length=25, hop_length=10, n_fft=400)
+FULL400 = dict(num_channels=[16, 32, 64, 128], num_freqs=201, hidden=512, segment_length=3200, num_layers=2,
+               num_inputs=3, kernel_size=3, dropout=0.0, sample_rate=16000, win_length=25, hop_length=10, n_fft=400)
+FULL512 = dict(FULL400, num_freqs=257, n_fft=512)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    CRN, utility = load_reference()
+    out = {}
+
+    # ---- G0: checkpoint key names / shapes of the live reference module -------------------------------
+    keys = {}
+    for name, cfg in (("tiny", TINY), ("full400", FULL400), ("full512", FULL512)):
+        m = CRN.TemporalCRN(**cfg)
+        keys[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        keys[name + "_deconv_dilations"] = [list(d.conv.dilation) for d in m.deconvlist]
+        keys[name + "_conv_dilations"] = [list(c.conv.dilation) for c in m.convlist]
+    with open(os.path.join(HERE, "crn_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+    # ---- G1: segmentation / over_add on integer ramps (exact) ------------------------------------------
+    for L in (1600, 3200, 8000, 4801, 49600):
+        x = torch.arange(2 * 3 * L, dtype=torch.float32).reshape(2, 3, L) % 8191.0
+        seg, gap = utility.segmentation(x, 3200)
+        out[f"seg_L{L}_out"] = t2n(seg) if L <= 8000 else t2n(seg)[::7, :, ::13]
+        out[f"seg_L{L}_gap"] = np.array([gap], np.int64)
+        B = 2
+        y = torch.arange(B * (seg.shape[0] // B) * 3200, dtype=torch.float32).reshape(B, -1, 3200) % 4093.0
+        oa = utility.over_add(y, gap)
+        out[f"ola_L{L}_out"] = t2n(oa) if L <= 8000 else t2n(oa)[:, ::11]
+
+    # ---- G2: STFT / ISTFT on one seeded window (torch.stft = de-facto oracle; parity unpinned) ---------
+    wav = torch.from_numpy(synth.hash_tensor("g2.wave", (2, 3, 3200)) * 0.5)
+    for name, cfg in (("400", FULL400), ("512", FULL512)):
+        m = CRN.TemporalCRN(**dict(cfg, num_channels=[2, 2, 2, 2], hidden=4))
+        sp = m.stft_trans(wav)  # [2,3,F,T,2]
+        out[f"stft{name}_out"] = t2n(sp)
+        spec_in = torch.from_numpy(synth.hash_tensor("g2.spec" + name, (2, cfg["num_freqs"], 21, 2)))
+        out[f"istft{name}_out"] = t2n(m.istft_trans(spec_in))
+    out["g2_wave"] = t2n(wav)
+
+    # ---- G3: per-block vectors -------------------------------------------------------------------------
+    with torch.no_grad():
+        # GlobalLayerNorm both modes
+        x = torch.from_numpy(synth.hash_tensor("g3.gln.x", (2, 6, 9, 21)))
+        g = CRN.GlobalLayerNorm(6, time=False)
+        g.weight.copy_(torch.from_numpy(1 + 0.25 * synth.hash_tensor("g3.gln.w", (1, 6, 1, 1))))
+        g.bias.copy_(torch.from_numpy(0.25 * synth.hash_tensor("g3.gln.b", (1, 6, 1, 1))))
+        out["gln_out"] = t2n(g(x))
+        x = torch.from_numpy(synth.hash_tensor("g3.glnl.x", (2, 1, 21, 10)))
+        g = CRN.GlobalLayerNorm(10, last=True, time=False)
+        g.weight.copy_(torch.from_numpy(1 + 0.25 * synth.hash_tensor("g3.glnl.w", (1, 1, 1, 10))))
+        g.bias.copy_(torch.from_numpy(0.25 * synth.hash_tensor("g3.glnl.b", (1, 1, 1, 10))))
+        out["gln_last_out"] = t2n(g(x))
+        # decompress_cIRM edge values
+        mvals = torch.tensor([-20.0, -10.0, -9.9, -9.89, -1.0, 0.0, 1e-6, 0.5, 9.89, 9.9, 10.0, 20.0])
+        out["cirm_in"] = t2n(mvals)
+        out["cirm_out"] = t2n(utility.decompress_cIRM(mvals))
+        # cal_si_snr / SI_SDR known answers
+        a = torch.from_numpy(synth.hash_tensor("g6.a", (2, 4000)))
+        b = a + 0.1 * torch.from_numpy(synth.hash_tensor("g6.b", (2, 4000)))
+        out["sisnr_in_a"], out["sisnr_in_b"] = t2n(a), t2n(b)
+        out["sisnr_out"] = t2n(utility.cal_si_snr(b, a, torch.tensor([4000, 3000])).reshape(1))
+
+    # ---- G4: tiny config end to end, incl. per-stage intermediates of forward() ------------------------
+    def run_e2e(tag, cfg, B, L, with_stages, cont_L=0):
+        model, spec, sd = build_ref_model(CRN, cfg, seed=0)
+        mix, _ = synth.synth_utterances(B, L + cont_L, cfg["num_inputs"], seed=7)
+        mix_t = torch.from_numpy(mix)
+        with torch.no_grad():
+            if with_stages:
+                stages = {}
+                hooks = []
+                for i, mod in enumerate(model.convlist):
+                    hooks.append(mod.register_forward_hook(lambda m_, i_, o_, i=i: stages.setdefault(f"enc{i}", []).append(t2n(o_))))
+                for i, mod in enumerate(model.deconvlist):
+                    hooks.append(mod.register_forward_hook(lambda m_, i_, o_, i=i: stages.setdefault(f"dec{i}", []).append(t2n(o_))))
+                hooks.append(model.gru.register_forward_hook(lambda m_, i_, o_: stages.setdefault("gru", []).append(t2n(o_))))
+                hooks.append(model.register_forward_hook(lambda m_, i_, o_: stages.setdefault("fwd", []).append(t2n(o_))))
+            y = model.realtime_process(mix_t[..., :L])
+            out[f"{tag}_out"] = t2n(y)
+            if with_stages:
+                for h in hooks:
+                    h.remove()
+                for k, v in stages.items():
+                    # keep segments 1 and 2 (segment 0 is the all-zero left pad)
+                    out[f"{tag}_stage_{k}"] = np.stack(v[1:3])
+            if cont_L:
+                y2 = model.realtime_process(mix_t[..., L:], True)  # flag=True continuation (CRN.py:568-575)
+                out[f"{tag}_cont_out"] = t2n(y2)
+        return model
+
+    run_e2e("tiny", TINY, B=2, L=8000, with_stages=True, cont_L=4800)
+    # ---- G5: full-size configs, hash weights (regenerated on the fly by the tests), output waveform only
+    run_e2e("full400", FULL400, B=2, L=8000, with_stages=False, cont_L=3200)
+    run_e2e("full512", FULL512, B=2, L=8000, with_stages=False)
+    # a ragged length (gap path) at B=1, the reference's own CPU-runnable case (BASELINE config 1)
+    model, _, _ = build_ref_model(CRN, FULL400, seed=0)
+    mix, _ = synth.synth_utterances(1, 5000, 3, seed=11)
+    with torch.no_grad():
+        out["full400_b1_L5000_out"] = t2n(model.realtime_process(torch.from_numpy(mix)))
+
+    np.savez_compressed(os.path.join(HERE, "crn_golden.npz"), **out)
+    sz = os.path.getsize(os.path.join(HERE, "crn_golden.npz"))
+    print("wrote crn_golden.npz", sz, "bytes;", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
