@@ -1,0 +1,106 @@
+/*
+ * se_engine.h - C ABI of the MI355X-native streaming speech-enhancement engine (libse_engine.so).
+ *
+ * The reference (KI-D/Speech-Enhancement-Mi) has no FFI: its plug-in point is the Python model class
+ * (README.md:22).  This ABI is what a drop-in TemporalCRN class binds instead of running torch ops; each
+ * entry point names the reference interface it replaces (file:line into the reference tree).  The
+ * reference-side binding (ctypes) is shown in INTEGRATION.md and shipped in
+ * speech_enhancement_mi_amd/crn.py.
+ *
+ * Conventions
+ *  - plain C, no torch types.  All tensor pointers are DEVICE pointers (HIP, fp32, contiguous) unless
+ *    a parameter says "host".  Pointers are borrowed for the duration of the call only.
+ *  - every call enqueues on the caller's hipStream_t (passed as void*; NULL = default stream) and does
+ *    not synchronise; the caller serialises calls per handle (the reference class is not re-entrant
+ *    either, CRN.py:325-337).
+ *  - return 0 on success, negative se_status on error; se_last_error() gives the message (the Python
+ *    shim re-raises it as RuntimeError, mirroring the reference's exceptions-only convention).
+ */
+#ifndef SE_ENGINE_H
+#define SE_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE_MAX_LEVELS 8
+
+typedef enum {
+    SE_OK = 0,
+    SE_ERR_ARG = -1,        /* bad argument / unsupported configuration */
+    SE_ERR_KEY = -2,        /* unknown checkpoint key */
+    SE_ERR_SHAPE = -3,      /* parameter shape mismatch */
+    SE_ERR_STATE = -4,      /* call order (step before reset, flag=True with another batch, ...) */
+    SE_ERR_HIP = -5,        /* HIP runtime error */
+    SE_ERR_PARAM_MISSING = -6 /* a weight was never loaded */
+} se_status;
+
+/* TemporalCRN.__init__ kwargs (CRN.py:415-417, config.yaml:205-217).  win/hop are in samples
+ * (= round(sample_rate/1000 * win_length_ms), the speechbrain STFT convention, CRN.py:421-425). */
+typedef struct {
+    int32_t num_levels;                 /* len(num_channels) */
+    int32_t channels[SE_MAX_LEVELS];    /* num_channels */
+    int32_t num_freqs;                  /* n_fft/2+1 */
+    int32_t hidden;
+    int32_t num_layers;                 /* GRU layers */
+    int32_t num_inputs;                 /* microphones M */
+    int32_t kernel_size;                /* 3 */
+    int32_t n_fft, win, hop;
+    int32_t segment_length;             /* K = 3200 */
+} se_config;
+
+typedef struct se_engine se_engine;
+
+/* TemporalCRN(**config['TemporalCRN'])  (CRN.py:415-451; train.py:58, predict.py:45) */
+int se_create(const se_config *cfg, int device, se_engine **out);
+void se_destroy(se_engine *e);
+/* message of the last failing call on this handle (or of se_create when e == NULL) */
+const char *se_last_error(const se_engine *e);
+
+/* load_state_dict(): one tensor per call, by reference checkpoint key (e.g.
+ * "convlist.0.conv.weight", "gru.sequence_model.weight_hh_l1").  `data` is a HOST pointer.
+ * The `net.0.*` aliases the reference's state_dict carries (CRN.py:314-316) are accepted. */
+int se_load_param(se_engine *e, const char *key, const float *host_data, const int64_t *shape, int ndim);
+
+/* TemporalCRN.reset() + lazy state allocation for B streams (CRN.py:498-503, 325-326). */
+int se_reset(se_engine *e, int batch);
+
+/* One hot-path step: all B streams advance by one K-sample window.
+ * wav_in [B, M, K] -> wav_out [B, K]  == istft_trans(forward(stft_trans(x)))  (CRN.py:505-520, 454-496) */
+int se_step(se_engine *e, const float *wav_in, float *wav_out, void *stream);
+
+/* TemporalCRN.realtime_process(mixture, flag) (CRN.py:560-589): mixture [B, M, L] -> out [B, L].
+ * flag == 0: reset + K/2 left pad (stripped again); flag != 0: carry state, B must match. */
+int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t length, int flag,
+                        float *out, void *stream);
+
+/* Per-stage entry points (parity tests; same arithmetic as inside se_step).
+ * se_stft:    stft_trans  (CRN.py:505-512): seg [n, K] -> spec [n, F, T, 2]   (n = B*M rows)
+ * se_istft:   istft_trans (CRN.py:514-520): spec [n, F, T, 2] -> wav [n, K]
+ * se_forward: TemporalCRN.forward (CRN.py:454-496): x [B, M, F, T, 2] -> y [B, F, T, 2]; stateful. */
+int se_stft(se_engine *e, const float *seg, int n, float *spec, void *stream);
+int se_istft(se_engine *e, const float *spec, int n, float *wav, void *stream);
+int se_forward(se_engine *e, const float *x, float *y, void *stream);
+
+/* Debug taps of the last forward, converted to the reference's [B, C, F, T] layout, copied to HOST.
+ * name: "feat", "enc0".."encN", "gru", "dec0".."decN".  Synchronises the stream.  *count = elements. */
+int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
+
+/* Streaming state hand-over: encoder time buffers "buf<i>" [B, Cin, F, 2d] and GRU
+ * hidden "h" [layers, B, H] in the reference's layouts, HOST pointers.  Synchronises. */
+int se_export_state(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
+int se_import_state(se_engine *e, const char *name, const float *host_in, int64_t count, void *stream);
+
+/* Introspection: algorithmic FLOPs per frame (dense contractions only) and geometry. */
+double se_flops_per_frame(const se_engine *e);
+int se_frames_per_segment(const se_engine *e); /* T */
+
+/* Names and launch counts of the kernels one se_step enqueues (for bench.py's roofline accounting). */
+int se_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE_ENGINE_H */

@@ -1,0 +1,210 @@
+// gemm.hip.h - dense fp32 GEMM on v_mfma_f32_32x32x2_f32 for the recurrent bottleneck (reference
+// SequenceModel, CRN.py:256-282): the GRU input projections for all T frames at once
+// ([B*T, in] x W_ih^T, aten::gru's first addmm) and the fc_output_layer ([B*T, H] x W_fc^T + ReLU).
+//
+// C[m][n] = act( sum_k A[m*lda + k] * W[n*ldw + k] + bias[n] ),  both operands K-contiguous
+// (PyTorch [out, in] weights are used as they are).  128x128 block tile, 4 waves as 2x2, each wave
+// 2x2 MFMA tiles of 32x32 (A and B fragments reused twice), K walked in 32-deep LDS chunks with a
+// +1 row pad (conflict-free ds_read_b32 for the lane->row fragment pattern).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.hip.h"
+
+namespace se {
+
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmKC = 32, kGemmLd = kGemmKC + 1;
+
+struct GemmArgs {
+    const float *A;
+    const float *W;
+    const float *bias;
+    float *C;
+    int M, N, K;
+    long lda, ldw, ldc;
+    int relu;
+};
+
+__device__ inline void gemm_stage(float *dst, const float *src, long ld, int rows_valid, int row0, int k0, int K, int tid) {
+    // 128 rows x 32 k: 1024 float4 slots, 4 per thread
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int slot = tid + it * 256;
+        const int r = slot >> 3, kq = (slot & 7) * 4;
+        const int row = row0 + r, k = k0 + kq;
+        float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (row < rows_valid) {
+            const float *p = src + (long)row * ld + k;
+            if (k + 3 < K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 q = *reinterpret_cast<const float4 *>(p);
+                v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+            } else {
+                if (k < K) v0 = p[0];
+                if (k + 1 < K) v1 = p[1];
+                if (k + 2 < K) v2 = p[2];
+                if (k + 3 < K) v3 = p[3];
+            }
+        }
+        float *d = dst + r * kGemmLd + kq;
+        d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(GemmArgs a) {
+    __shared__ float As[kGemmBM * kGemmLd];
+    __shared__ float Ws[kGemmBN * kGemmLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    for (int k0 = 0; k0 < a.K; k0 += kGemmKC) {
+        __syncthreads();
+        gemm_stage(As, a.A, a.lda, a.M, m0, k0, a.K, tid);
+        gemm_stage(Ws, a.W, a.ldw, a.N, n0, k0, a.K, tid);
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kGemmKC; kk += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) av[i] = As[(wm + i * 32 + l31) * kGemmLd + kk + half];
+#pragma unroll
+            for (int j = 0; j < 2; j++) bv[j] = Ws[(wn + j * 32 + l31) * kGemmLd + kk + half];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D layout: column (n) on lanes, rows (m) in registers
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = n0 + wn + j * 32 + l31;
+            if (n >= a.N) continue;
+            const float bs = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) {
+                    float v = acc[i][j][r] + bs;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.C[(long)m * a.ldc + n] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One GRU time step for all streams (torch.nn.GRU cell, gate order r,z,n; reference CRN.py:269):
+//   gh = h_prev W_hh^T + b_hh ;  r = s(gi_r + gh_r) ; z = s(gi_z + gh_z) ; n = tanh(gi_n + r * gh_n)
+//   h  = (1 - z) n + z h_prev
+// gi (= x_t W_ih^T + b_ih) is precomputed for all T by k_gemm_tn.  The three gate columns of one hidden
+// unit are kept in the same wave so the gate math is a register epilogue of the MFMAs (no gh round trip).
+// Workgroup = 32 streams x 16 hidden units; 4 waves = 2 row tiles x 2 K halves (split-K through LDS)
+// so a B=256, H=512 step exposes 256 workgroups x 4 waves = one wave per SIMD of the chip.
+// v_mfma_f32_16x16x4_f32: A lane (row=l&15, k=l>>4), B lane (k=l>>4, col=l&15); each lane fetches 4
+// consecutive k per 16-B load, so MFMA s of a 16-deep block contracts k = 4*(l>>4)+s on both operands.
+struct GruStepArgs {
+    const float *gi;     // + t*3H already applied; row stride gi_ld
+    long gi_ld;
+    const float *hprev;  // [B][H]
+    const float *whh;    // [3H][H]
+    const float *bhh;    // [3H]
+    float *hout;         // [B][H]
+    float *seq;          // + t*H applied; row stride seq_ld
+    long seq_ld;
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) {
+    __shared__ float red[2][3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = wave & 1, kh = wave >> 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32 + rt * 16;
+    const int H = a.H;
+    const int nkb = (H + 15) >> 4;
+    const int kb0 = kh ? (nkb >> 1) : 0, kb1 = kh ? nkb : (nkb >> 1);
+    const int arow = r0 + l15;
+    const bool arow_ok = arow < a.B;
+    const int n = n0 + l15;
+    const bool n_ok = n < H;
+    const float *ap = a.hprev + (long)(arow_ok ? arow : 0) * H;
+    const float *bp0 = a.whh + (long)(n_ok ? n : 0) * H;
+    const float *bp1 = bp0 + (long)H * H;
+    const float *bp2 = bp1 + (long)H * H;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    auto ld4 = [&](const float *p, int k, bool ok) -> float4 {
+        if (!ok || k >= H) return zero4;
+        if (k + 3 < H) return *reinterpret_cast<const float4 *>(p + k);
+        float4 v = zero4;
+        v.x = p[k];
+        if (k + 1 < H) v.y = p[k + 1];
+        if (k + 2 < H) v.z = p[k + 2];
+        return v;
+    };
+    float4 av, b0, b1, b2;
+    if (kb0 < kb1) {
+        const int k = kb0 * 16 + kq * 4;
+        av = ld4(ap, k, arow_ok); b0 = ld4(bp0, k, n_ok); b1 = ld4(bp1, k, n_ok); b2 = ld4(bp2, k, n_ok);
+    }
+    for (int kb = kb0; kb < kb1; kb++) {
+        const float4 ca = av, c0 = b0, c1 = b1, c2 = b2;
+        if (kb + 1 < kb1) {
+            const int k = (kb + 1) * 16 + kq * 4;
+            av = ld4(ap, k, arow_ok); b0 = ld4(bp0, k, n_ok); b1 = ld4(bp1, k, n_ok); b2 = ld4(bp2, k, n_ok);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c1.x, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c2.x, acc2, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c1.y, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c2.y, acc2, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c1.z, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c2.z, acc2, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c1.w, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c2.w, acc2, 0, 0, 0);
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[rt][0][r][lane] = acc0[r];
+            red[rt][1][r][lane] = acc1[r];
+            red[rt][2][r][lane] = acc2[r];
+        }
+    }
+    __syncthreads();
+    if (kh == 0 && n_ok) {
+        const float bh_r = a.bhh[n], bh_z = a.bhh[H + n], bh_n = a.bhh[2 * H + n];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = r0 + kq * 4 + r;  // D layout: col = lane&15, row = (lane>>4)*4 + reg
+            if (row >= a.B) continue;
+            const float gh_r = acc0[r] + red[rt][0][r][lane] + bh_r;
+            const float gh_z = acc1[r] + red[rt][1][r][lane] + bh_z;
+            const float gh_n = acc2[r] + red[rt][2][r][lane] + bh_n;
+            const float *gi = a.gi + (long)row * a.gi_ld;
+            const float rg = 1.0f / (1.0f + expf(-(gi[n] + gh_r)));
+            const float zg = 1.0f / (1.0f + expf(-(gi[H + n] + gh_z)));
+            const float ng = tanhf(gi[2 * H + n] + rg * gh_n);
+            const float hp = a.hprev[(long)row * H + n];
+            const float hn = (1.0f - zg) * ng + zg * hp;
+            a.hout[(long)row * H + n] = hn;
+            a.seq[(long)row * a.seq_ld + n] = hn;
+        }
+    }
+}
+
+}  // namespace se

@@ -1,0 +1,186 @@
+// norm.hip.h - per-stream global layer norm and the pointwise stages fused around it.
+//
+// Reference: GlobalLayerNorm(time=False).forward (CRN.py:135-149): per sample, mean and BIASED variance
+// over every non-batch element (two passes, like the reference), y = (x - mu) / (sqrt(var + 1e-8) + 1e-8) * w + b.
+// One workgroup (1024 threads = 16 wavefronts) owns one stream's tensor (<= ~180 KB, L2 resident after
+// the first pass); reductions are wavefront shuffles + one LDS hop, combined in double.
+// Fused variants:
+//   k_featurize  - |X|, arctan phase differences (CRN.py:463-467)
+//   k_gln        - norm + affine, optional re-layout ([C][T][F] <-> GRU's [T][C*F])
+//   k_dec_blend  - decoder skip gate: m = sigmoid(gLN(conv_mask(res))), out = m*relu(conv_res(res)) + (1-m)*pad(gLN(y))
+//                  (CRN.py:387-396)
+//   k_final_mask - gLN of the last decoder block, decompress_cIRM (utility.py:439-442), complex multiply
+//                  with the mic-0 spectrum (CRN.py:491-495)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fft_lds.h"
+
+namespace se {
+
+constexpr float kEps = 1e-8f;  // CRN.py:11
+
+__device__ inline double block_sum(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();  // protect red from a previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < nw; i++) s += red[i];
+    return s;
+}
+
+// mean and 1/(sqrt(var+eps)+eps) of n contiguous floats (two-pass, biased variance)
+__device__ inline void stream_stats(const float *x, long n, double *red, float &mean, float &inv) {
+    float part = 0.0f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) part += x[i];
+    const double s = block_sum((double)part, red);
+    mean = (float)(s / (double)n);
+    float p2 = 0.0f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = x[i] - mean;
+        p2 += d * d;
+    }
+    const double q = block_sum((double)p2, red);
+    const float var = (float)(q / (double)n);
+    inv = 1.0f / (sqrtf(var + kEps) + kEps);
+}
+
+// ---- featurise: spec (b, m, t, f) -> feat [B][2M-1][T][F] --------------------------------------
+struct FeatArgs {
+    const cf2 *spec;
+    long sB, sM, sT, sF;  // strides in cf2 units
+    float *feat;
+    int M, T, F;
+};
+
+__global__ void k_featurize(FeatArgs a) {
+    const int b = blockIdx.y;
+    const int TF = a.T * a.F;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TF) return;
+    const int t = i / a.F, f = i - t * a.F;
+    const cf2 *s = a.spec + (long)b * a.sB + (long)t * a.sT + (long)f * a.sF;
+    float *o = a.feat + (long)b * (2 * a.M - 1) * TF + i;
+    float ang0 = 0.0f;
+    for (int m = 0; m < a.M; m++) {
+        const cf2 v = s[(long)m * a.sM];
+        o[(long)m * TF] = sqrtf(v.x * v.x + v.y * v.y + 1e-10f);
+        const float ang = atanf(v.y / (v.x + kEps) + kEps);  // arctan, not atan2 (CRN.py:464)
+        if (m == 0) ang0 = ang;
+        else o[(long)(a.M + m - 1) * TF] = ang0 - ang;
+    }
+}
+
+// ---- gLN with optional re-layout ---------------------------------------------------------------
+struct GlnArgs {
+    const float *x;  // per stream n contiguous floats
+    float *y;
+    const float *w, *b;
+    long n;
+    int mode;  // 0: [C][T][F] -> same, affine per C | 1: [C][T][F] -> [T][C*F], affine per C
+               // 2: [T][D=C*F] -> [C][T][F], affine per D (GlobalLayerNorm(last=True), CRN.py:127-129)
+    int C, T, F;
+};
+
+__global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
+    __shared__ double red[16];
+    const float *x = a.x + (long)blockIdx.x * a.n;
+    float *y = a.y + (long)blockIdx.x * a.n;
+    float mean, inv;
+    stream_stats(x, a.n, red, mean, inv);
+    const int TF = a.T * a.F, F = a.F, T = a.T, C = a.C;
+    if (a.mode == 0) {
+        for (long i = threadIdx.x; i < a.n; i += blockDim.x) {
+            const int c = (int)(i / TF);
+            y[i] = (x[i] - mean) * inv * a.w[c] + a.b[c];
+        }
+    } else if (a.mode == 1) {
+        for (long i = threadIdx.x; i < a.n; i += blockDim.x) {
+            const int c = (int)(i / TF), r = (int)(i - (long)c * TF), t = r / F, f = r - t * F;
+            y[((long)t * C + c) * F + f] = (x[i] - mean) * inv * a.w[c] + a.b[c];
+        }
+    } else {
+        const int D = C * F;
+        for (long i = threadIdx.x; i < a.n; i += blockDim.x) {
+            const int t = (int)(i / D), d = (int)(i - (long)t * D), c = d / F, f = d - c * F;
+            y[((long)c * T + t) * F + f] = (x[i] - mean) * inv * a.w[d] + a.b[d];
+        }
+    }
+}
+
+// ---- decoder skip blend --------------------------------------------------------------------------
+struct BlendArgs {
+    const float *y;   // deconv out, ReLU'd, [B][Co][T][Fo]
+    const float *uv;  // [B][2Co][T][Fr]: u = conv_mask(res) raw, v = relu(conv_res(res))
+    float *out;       // [B][Co][T][Fr]
+    const float *nw, *nb;    // norm affine of y       (deconvlist.j.norm)
+    const float *mnw, *mnb;  // norm affine of u       (deconvlist.j.residualnorm)
+    int Co, T, Fo, Fr;
+};
+
+__global__ __launch_bounds__(1024) void k_dec_blend(BlendArgs a) {
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    const long ny = (long)a.Co * a.T * a.Fo, nu = (long)a.Co * a.T * a.Fr;
+    const float *y = a.y + b * ny;
+    const float *u = a.uv + (long)b * 2 * nu;
+    const float *v = u + nu;
+    float my, iy, mu, iu;
+    stream_stats(y, ny, red, my, iy);
+    stream_stats(u, nu, red, mu, iu);
+    float *o = a.out + b * nu;
+    const int TFr = a.T * a.Fr;
+    for (long i = threadIdx.x; i < nu; i += blockDim.x) {
+        const int c = (int)(i / TFr), r = (int)(i - (long)c * TFr), t = r / a.Fr, f = r - t * a.Fr;
+        // pad with zeros (after the norm) or crop to the skip's F (CRN.py:389-393)
+        const float yv = f < a.Fo ? (y[((long)c * a.T + t) * a.Fo + f] - my) * iy * a.nw[c] + a.nb[c] : 0.0f;
+        const float uu = (u[i] - mu) * iu * a.mnw[c] + a.mnb[c];
+        const float m = 1.0f / (1.0f + expf(-uu));
+        o[i] = m * v[i] + (1.0f - m) * yv;
+    }
+}
+
+// ---- last decoder block: gLN, decompress cIRM, complex multiply with mic 0 -------------------------
+struct MaskArgs {
+    const float *y;  // [B][2][T][F] ReLU'd deconv output
+    const float *nw, *nb;
+    const cf2 *spec;  // mic-0 spectrum, element (b, t, f) at b*sB + t*sT + f*sF
+    long sB, sT, sF;
+    cf2 *out;  // element (b, t, f) at b*oB + t*oT + f*oF
+    long oB, oT, oF;
+    int T, F;
+};
+
+__device__ inline float decompress_cirm(float m) {
+    m = m >= 9.9f ? 9.9f : (m <= -9.9f ? -9.9f : m);
+    return -10.0f * logf((10.0f - m) / (10.0f + m));
+}
+
+__global__ __launch_bounds__(1024) void k_final_mask(MaskArgs a) {
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    const int TF = a.T * a.F;
+    const float *y = a.y + (long)b * 2 * TF;
+    float mean, inv;
+    stream_stats(y, 2L * TF, red, mean, inv);
+    for (int i = threadIdx.x; i < TF; i += blockDim.x) {
+        const int t = i / a.F, f = i - t * a.F;
+        const float mr = decompress_cirm((y[i] - mean) * inv * a.nw[0] + a.nb[0]);
+        const float mi = decompress_cirm((y[TF + i] - mean) * inv * a.nw[1] + a.nb[1]);
+        const cf2 n = a.spec[(long)b * a.sB + (long)t * a.sT + (long)f * a.sF];
+        a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * n.x - mi * n.y, mi * n.x + mr * n.y};
+    }
+}
+
+// ---- layout converters for the debug taps / state hand-over ([B][C][T][F] <-> reference [B][C][F][T]) ----
+__global__ void k_ctf_to_cft(const float *src, float *dst, long BC, int T, int F) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC * T * F) return;
+    const long bc = i / ((long)T * F);
+    const int r = (int)(i - bc * T * F), t = r / F, f = r - t * F;
+    dst[(bc * F + f) * T + t] = src[i];
+}
+
+}  // namespace se

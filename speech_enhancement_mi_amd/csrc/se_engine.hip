@@ -1,0 +1,767 @@
+// se_engine.hip - persistent stream-batch engine behind the C ABI of include/se_engine.h.
+//
+// One engine owns, on one MI355X: all weights (re-laid-out once for the kernels), all per-stream
+// state for B streams (ping-pong activation tensors that double as the reference's conv time buffers,
+// GRU hidden state) and a fixed kernel sequence that advances every stream by one K-sample window:
+//
+//   k_stft -> k_featurize -> 4x (k_conv_igemm + k_gln) -> 2x (k_gemm_tn + T x k_gru_step) -> k_gemm_tn
+//   -> k_gln -> 4x (k_conv_igemm even/odd [+ 1x1 skip GEMM + k_dec_blend]) -> k_final_mask -> k_istft
+//
+// Reference: TemporalCRN.forward / realtime_process (CRN.py:454-496, 560-589).  No CPU fallback exists:
+// every entry point fails with SE_ERR_HIP if the device path is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/se_engine.h"
+#include "conv_igemm.hip.h"
+#include "fft_lds.h"
+#include "gemm.hip.h"
+#include "norm.hip.h"
+#include "stft.hip.h"
+
+using namespace se;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    float *p = nullptr;
+    size_t n = 0;
+};
+
+struct ConvPlan {
+    ConvArgs a{};  // pointers filled per launch
+    int NT = 1;
+    int grid_x = 0;
+    size_t lds = 0;
+    DevBuf w, bias;
+    bool active = false;
+};
+
+struct Level {  // one encoder/decoder level
+    ConvPlan enc;
+    ConvPlan dec_even, dec_odd, skip;
+    DevBuf enc_nw, enc_nb, dec_nw, dec_nb, dec_mnw, dec_mnb;
+};
+
+}  // namespace
+
+struct se_engine {
+    se_config c{};
+    int device = 0;
+    int L = 0, T = 0, D = 0, M = 0, K = 0, N = 0, H = 0, NL = 0;
+    int F[SE_MAX_LEVELS + 1]{};
+    int Ch[SE_MAX_LEVELS + 1]{};  // Ch[0] = 2M-1, Ch[i+1] = channels[i]
+    std::string err;
+    std::map<std::string, std::vector<float>> params;  // host copies by canonical key
+    std::map<std::string, std::vector<int64_t>> shapes;
+    bool weights_ready = false;
+    size_t conv_lds_budget = 48 * 1024;
+
+    // constant tables
+    DevBuf window, env, tw;
+    FftPlan plan{};
+
+    // weights
+    Level lv[SE_MAX_LEVELS];  // enc i at lv[i]; decoder j at lv[j] (dec_* members)
+    DevBuf wih[4], whh[4], bih[4], bhh[4], fcw, fcb, gnw, gnb;
+
+    // state + activations for B streams
+    int B = 0;
+    int parity = 0;  // index of the "current" ping-pong half
+    DevBuf spec, maskspec;
+    DevBuf xin[SE_MAX_LEVELS][2];  // encoder level inputs (xin[0] = features), ping-pong
+    DevBuf enc_raw[SE_MAX_LEVELS];
+    DevBuf gru_in, gi, seq[2], hbuf[4][2], fc_out, dec_in;
+    int hcur[4]{};
+    DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
+    DevBuf yseg, scratch;
+};
+
+namespace {
+
+int fail(se_engine *e, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHECK(e, call)                                                                      \
+    do {                                                                                       \
+        hipError_t _st = (call);                                                               \
+        if (_st != hipSuccess)                                                                 \
+            return fail(e, SE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+int dev_alloc(se_engine *e, DevBuf &b, size_t n) {
+    if (b.p && b.n >= n) return 0;
+    if (b.p) HIPCHECK(e, hipFree(b.p));
+    b.p = nullptr;
+    b.n = 0;
+    HIPCHECK(e, hipMalloc(reinterpret_cast<void **>(&b.p), (n ? n : 1) * sizeof(float)));
+    b.n = n;
+    return 0;
+}
+
+int dev_upload(se_engine *e, DevBuf &b, const std::vector<float> &h) {
+    int rc = dev_alloc(e, b, h.size());
+    if (rc) return rc;
+    HIPCHECK(e, hipMemcpy(b.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void dev_free(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.n = 0;
+}
+
+std::string canon(const char *key) {
+    std::string k(key);
+    size_t pos = k.find(".net.0.");
+    if (pos != std::string::npos) k.replace(pos, 7, ".conv.");  // CRN.py:314-316 alias
+    return k;
+}
+
+const std::vector<float> *param(se_engine *e, const std::string &key, size_t expect) {
+    auto it = e->params.find(key);
+    if (it == e->params.end()) {
+        fail(e, SE_ERR_PARAM_MISSING, "parameter %s was never loaded", key.c_str());
+        return nullptr;
+    }
+    if (it->second.size() != expect) {
+        fail(e, SE_ERR_SHAPE, "parameter %s has %zu elements, expected %zu", key.c_str(), it->second.size(), expect);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// ---- conv planning --------------------------------------------------------------------------------
+// taps: list of (kf, kt) with their patch offsets; wsel(ci, co, kf, kt) fetches the reference weight.
+template <class WSel>
+int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy, int s, int os, int oo, int colpad,
+              int tlo_off, int rows_extra, int St, const std::vector<std::array<int, 4>> &taps /*kf,kt,rowoff,coloff*/,
+              WSel wsel, const std::vector<float> &bias, int relu_lo, int relu_hi) {
+    pl.active = FP > 0;
+    if (!pl.active) return 0;
+    const int T = e->T;
+    const int CoPad = (Co + 31) / 32 * 32;
+    if (CoPad > 128) return fail(e, SE_ERR_ARG, "conv with %d output channels is not supported (max 128 per GEMM)", Co);
+    const int MT = CoPad / 32;
+    if (MT == 3) return fail(e, SE_ERR_ARG, "conv output channels %d need 3 row tiles (unsupported)", Co);
+    const int NCG = 4 / MT, NTmax = 4;
+    const int P = T * FP, tiles = (P + 31) / 32;
+    const int n_wg = (tiles + NCG * NTmax - 1) / (NCG * NTmax);
+    const int tpw = (tiles + n_wg - 1) / n_wg;
+    const int NT = (tpw + NCG - 1) / NCG;
+    const int ntap = (int)taps.size();
+    int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
+    if (rows_pos > T) rows_pos = T;
+    const int Rmax = rows_pos + rows_extra;
+    const int CiPad = (Ci + 1) / 2 * 2;
+    auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * CoPad + (size_t)cc * Rmax * St); };
+    int CC = CiPad;
+    while (CC > 2 && bytes(CC) > e->conv_lds_budget) CC -= 2;
+    int nchunk = (CiPad + CC - 1) / CC;
+    CC = ((CiPad + nchunk - 1) / nchunk + 1) / 2 * 2;
+    nchunk = (CiPad + CC - 1) / CC;
+    if (bytes(CC) > 150 * 1024) return fail(e, SE_ERR_ARG, "conv tile does not fit LDS (%zu bytes)", bytes(CC));
+    ConvArgs &a = pl.a;
+    a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
+    a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.rows_extra = rows_extra;
+    a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+    a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+    for (int t = 0; t < ntap; t++) { a.rowoff[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
+    pl.NT = NT;
+    pl.grid_x = n_wg;
+    pl.lds = bytes(CC);
+    std::vector<float> w((size_t)nchunk * ntap * CC * CoPad, 0.0f);
+    for (int ch = 0; ch < nchunk; ch++)
+        for (int t = 0; t < ntap; t++)
+            for (int c = 0; c < CC; c++) {
+                const int ci = ch * CC + c;
+                if (ci >= Ci) continue;
+                float *dst = &w[(((size_t)ch * ntap + t) * CC + c) * CoPad];
+                for (int co = 0; co < Co; co++) dst[co] = wsel(ci, co, taps[t][0], taps[t][1]);
+            }
+    int rc = dev_upload(e, pl.w, w);
+    if (rc) return rc;
+    return dev_upload(e, pl.bias, bias);
+}
+
+int prepare_weights(se_engine *e) {
+    if (e->weights_ready) return 0;
+    const int L = e->L, H = e->H, D = e->D;
+    for (int i = 0; i < L; i++) {
+        const int Ci = e->Ch[i], Co = e->Ch[i + 1], Fi = e->F[i], Fo = e->F[i + 1], d = 1 << i;
+        const std::string p = "convlist." + std::to_string(i) + ".";
+        auto *w = param(e, p + "conv.weight", (size_t)Co * Ci * 15);
+        auto *b = param(e, p + "conv.bias", Co);
+        auto *nw = param(e, p + "norm.weight", Co);
+        auto *nb = param(e, p + "norm.bias", Co);
+        if (!w || !b || !nw || !nb) return SE_ERR_PARAM_MISSING;
+        std::vector<std::array<int, 4>> taps;
+        for (int kf = 0; kf < 5; kf++)
+            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, kt * d, kf});
+        const float *wp = w->data();
+        int rc = plan_conv(e, e->lv[i].enc, Ci, Co, Fo, Fi, Fo, 2, 1, 0, 2, -2 * d, 2 * d, Fi + 4, taps,
+                           [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; },
+                           *b, 0, Co);
+        if (rc) return rc;
+        if ((rc = dev_upload(e, e->lv[i].enc_nw, *nw))) return rc;
+        if ((rc = dev_upload(e, e->lv[i].enc_nb, *nb))) return rc;
+    }
+    for (int j = 0; j < L; j++) {
+        const int lvl = L - 1 - j;
+        const int Ci = e->Ch[lvl + 1], Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1], Fo = 2 * Fi - 1, d = 1 << j;
+        const std::string p = "deconvlist." + std::to_string(j) + ".";
+        auto *w = param(e, p + "conv.weight", (size_t)Co * Ci * 15);
+        auto *b = param(e, p + "conv.bias", Co);
+        auto *nw = param(e, p + "norm.weight", Co);
+        auto *nb = param(e, p + "norm.bias", Co);
+        if (!w || !b || !nw || !nb) return SE_ERR_PARAM_MISSING;
+        const float *wp = w->data();
+        auto wsel = [=](int ci, int co, int kf, int kt) { return wp[(((size_t)ci * Co + co) * 5 + kf) * 3 + kt]; };
+        std::vector<std::array<int, 4>> te, to;
+        for (int kf = 0; kf < 5; kf += 2)
+            for (int kt = 0; kt < 3; kt++) te.push_back({kf, kt, (2 - kt) * d, 2 - kf / 2});
+        for (int kf = 1; kf < 5; kf += 2)
+            for (int kt = 0; kt < 3; kt++) to.push_back({kf, kt, (2 - kt) * d, 1 + (3 - kf) / 2});
+        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 2 * d, Fi + 2, te, wsel, *b, 0, Co);
+        if (rc) return rc;
+        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 2 * d, Fi + 2, to, wsel, *b, 0, Co);
+        if (rc) return rc;
+        if ((rc = dev_upload(e, e->lv[j].dec_nw, *nw))) return rc;
+        if ((rc = dev_upload(e, e->lv[j].dec_nb, *nb))) return rc;
+        if (lvl > 0) {  // skip path exists (CRN.py:485-487)
+            auto *mw = param(e, p + "residualmask.weight", (size_t)Co * Co);
+            auto *mb = param(e, p + "residualmask.bias", Co);
+            auto *rw = param(e, p + "residual.weight", (size_t)Co * Co);
+            auto *rb = param(e, p + "residual.bias", Co);
+            auto *mnw = param(e, p + "residualnorm.weight", Co);
+            auto *mnb = param(e, p + "residualnorm.bias", Co);
+            if (!mw || !mb || !rw || !rb || !mnw || !mnb) return SE_ERR_PARAM_MISSING;
+            const float *mwp = mw->data(), *rwp = rw->data();
+            std::vector<float> bias2(2 * Co);
+            for (int c = 0; c < Co; c++) { bias2[c] = (*mb)[c]; bias2[Co + c] = (*rb)[c]; }
+            std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
+            const int Fr = e->F[lvl];
+            rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 0, Fr, t1,
+                           [=](int ci, int co, int, int) { return co < Co ? mwp[(size_t)co * Co + ci] : rwp[(size_t)(co - Co) * Co + ci]; },
+                           bias2, Co, 2 * Co);
+            if (rc) return rc;
+            if ((rc = dev_upload(e, e->lv[j].dec_mnw, *mnw))) return rc;
+            if ((rc = dev_upload(e, e->lv[j].dec_mnb, *mnb))) return rc;
+        }
+    }
+    for (int l = 0; l < e->NL; l++) {
+        const std::string s = std::to_string(l);
+        const size_t in = l == 0 ? D : H;
+        auto *a = param(e, "gru.sequence_model.weight_ih_l" + s, 3 * (size_t)H * in);
+        auto *b = param(e, "gru.sequence_model.weight_hh_l" + s, 3 * (size_t)H * H);
+        auto *c = param(e, "gru.sequence_model.bias_ih_l" + s, 3 * (size_t)H);
+        auto *d = param(e, "gru.sequence_model.bias_hh_l" + s, 3 * (size_t)H);
+        if (!a || !b || !c || !d) return SE_ERR_PARAM_MISSING;
+        int rc;
+        if ((rc = dev_upload(e, e->wih[l], *a)) || (rc = dev_upload(e, e->whh[l], *b)) ||
+            (rc = dev_upload(e, e->bih[l], *c)) || (rc = dev_upload(e, e->bhh[l], *d)))
+            return rc;
+    }
+    {
+        auto *a = param(e, "gru.fc_output_layer.weight", (size_t)D * H);
+        auto *b = param(e, "gru.fc_output_layer.bias", D);
+        auto *c = param(e, "gru.norm.weight", D);
+        auto *d = param(e, "gru.norm.bias", D);
+        if (!a || !b || !c || !d) return SE_ERR_PARAM_MISSING;
+        int rc;
+        if ((rc = dev_upload(e, e->fcw, *a)) || (rc = dev_upload(e, e->fcb, *b)) || (rc = dev_upload(e, e->gnw, *c)) ||
+            (rc = dev_upload(e, e->gnb, *d)))
+            return rc;
+    }
+    e->weights_ready = true;
+    return 0;
+}
+
+int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st) {
+    if (!pl.active) return 0;
+    ConvArgs a = pl.a;
+    a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p;
+    dim3 grid(pl.grid_x, e->B);
+    switch (pl.NT) {
+        case 1: hipLaunchKernelGGL(k_conv_igemm<1>, grid, dim3(256), pl.lds, st, a); break;
+        case 2: hipLaunchKernelGGL(k_conv_igemm<2>, grid, dim3(256), pl.lds, st, a); break;
+        case 3: hipLaunchKernelGGL(k_conv_igemm<3>, grid, dim3(256), pl.lds, st, a); break;
+        default: hipLaunchKernelGGL(k_conv_igemm<4>, grid, dim3(256), pl.lds, st, a); break;
+    }
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw, const float *bias, float *C, long ldc,
+                int Mr, int Nc, int Kd, int relu, hipStream_t st) {
+    GemmArgs g{A, W, bias, C, Mr, Nc, Kd, lda, ldw, ldc, relu};
+    dim3 grid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
+    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, g);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+int launch_gln(se_engine *e, const float *x, float *y, const float *w, const float *b, long n, int mode, int C, int T,
+               int F, hipStream_t st) {
+    GlnArgs g{x, y, w, b, n, mode, C, T, F};
+    hipLaunchKernelGGL(k_gln, dim3(e->B), dim3(1024), 0, st, g);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+// TemporalCRN.forward on device.  spec: (b, m, t, f) strides; out: (b, t, f) strides (cf2 units).
+int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long sF, cf2 *out, long oB, long oT, long oF,
+                hipStream_t st) {
+    const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+    int rc;
+    e->parity ^= 1;
+    const int cur = e->parity, prev = cur ^ 1;
+    {  // features (CRN.py:463-467)
+        FeatArgs f{spec, sB, sM, sT, sF, e->xin[0][cur].p, e->M, T, e->F[0]};
+        const int TF = T * e->F[0];
+        hipLaunchKernelGGL(k_featurize, dim3((TF + 255) / 256, B), dim3(256), 0, st, f);
+        HIPCHECK(e, hipGetLastError());
+    }
+    for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474)
+        const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
+        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st))) return rc;
+        const long n = (long)Co * T * Fo;
+        if (i + 1 < L) rc = launch_gln(e, e->enc_raw[i].p, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 0, Co, T, Fo, st);
+        else rc = launch_gln(e, e->enc_raw[i].p, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 1, Co, T, Fo, st);
+        if (rc) return rc;
+    }
+    // bottleneck (CRN.py:476-481, 256-282)
+    const float *layer_in = e->gru_in.p;
+    long in_dim = D;
+    for (int l = 0; l < e->NL; l++) {
+        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st))) return rc;
+        float *seq = e->seq[l & 1].p;
+        for (int t = 0; t < T; t++) {
+            const int hc = e->hcur[l];
+            GruStepArgs g{e->gi.p + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
+                          e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
+            hipLaunchKernelGGL(k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
+            e->hcur[l] = hc ^ 1;
+        }
+        HIPCHECK(e, hipGetLastError());
+        layer_in = seq;
+        in_dim = H;
+    }
+    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st))) return rc;
+    if ((rc = launch_gln(e, e->fc_out.p, e->dec_in.p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st))) return rc;
+    // decoder (CRN.py:483-489)
+    const float *x = e->dec_in.p;
+    for (int j = 0; j < L; j++) {
+        const int lvl = L - 1 - j;
+        const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1], Fo = 2 * Fi - 1;
+        if ((rc = launch_conv(e, e->lv[j].dec_even, x, nullptr, e->dec_raw[j].p, st))) return rc;
+        if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st))) return rc;
+        if (lvl > 0) {
+            const int Fr = e->F[lvl];
+            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st))) return rc;
+            BlendArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
+                         e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, Co, T, Fo, Fr};
+            hipLaunchKernelGGL(k_dec_blend, dim3(B), dim3(1024), 0, st, bl);
+            HIPCHECK(e, hipGetLastError());
+            x = e->dec_out[j].p;
+        } else {
+            if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
+            MaskArgs m{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
+            hipLaunchKernelGGL(k_final_mask, dim3(B), dim3(1024), 0, st, m);
+            HIPCHECK(e, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int M, long off, long Lsrc, int rows,
+                cf2 *spec, long sR, long sT, long sF, hipStream_t st) {
+    StftArgs a{};
+    a.src = src; a.strideB = strideB; a.strideM = strideM; a.M = M; a.off = off; a.L = Lsrc;
+    a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
+    a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF;
+    a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+    hipLaunchKernelGGL(k_stft, dim3(rows), dim3(256), stft_lds_bytes(e->K, e->N), st, a);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int rows, float *wav, long wav_ld, hipStream_t st) {
+    IstftArgs a{};
+    a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF; a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
+    a.wav = wav; a.wav_ld = wav_ld; a.window = e->window.p; a.env = e->env.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+    hipLaunchKernelGGL(k_istft, dim3(rows), dim3(256), istft_lds_bytes(e->T, e->N), st, a);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+int ensure_ready(se_engine *e) {
+    if (!e) return SE_ERR_ARG;
+    HIPCHECK(e, hipSetDevice(e->device));
+    return prepare_weights(e);
+}
+
+}  // namespace
+
+extern "C" {
+
+int se_abi_version(void) { return 1; }
+
+const char *se_last_error(const se_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int se_create(const se_config *cfg, int device, se_engine **out) {
+    if (!cfg || !out) return fail(nullptr, SE_ERR_ARG, "null argument");
+    *out = nullptr;
+    const int L = cfg->num_levels;
+    if (L < 1 || L > SE_MAX_LEVELS) return fail(nullptr, SE_ERR_ARG, "num_levels %d out of range", L);
+    if (cfg->kernel_size != 3) return fail(nullptr, SE_ERR_ARG, "kernel_size %d unsupported (reference config uses 3)", cfg->kernel_size);
+    if (cfg->num_layers < 1 || cfg->num_layers > 4) return fail(nullptr, SE_ERR_ARG, "num_layers %d out of range", cfg->num_layers);
+    if (cfg->hidden <= 0 || cfg->hidden % 4) return fail(nullptr, SE_ERR_ARG, "hidden must be a positive multiple of 4 (16-byte operand loads)");
+    if (cfg->n_fft % 2 || cfg->num_freqs != cfg->n_fft / 2 + 1) return fail(nullptr, SE_ERR_ARG, "num_freqs must be n_fft/2+1 (CRN.py:511)");
+    if (cfg->win > cfg->n_fft || cfg->hop <= 0 || cfg->segment_length % cfg->hop) return fail(nullptr, SE_ERR_ARG, "bad STFT geometry");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SE_ERR_HIP, "no HIP device available: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, SE_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    se_engine *e = new se_engine();
+    e->c = *cfg;
+    e->device = device;
+    e->L = L; e->M = cfg->num_inputs; e->K = cfg->segment_length; e->N = cfg->n_fft; e->H = cfg->hidden; e->NL = cfg->num_layers;
+    e->T = 1 + cfg->segment_length / cfg->hop;
+    e->F[0] = cfg->num_freqs;
+    e->Ch[0] = 2 * cfg->num_inputs - 1;
+    for (int i = 0; i < L; i++) { e->F[i + 1] = (e->F[i] - 1) / 2 + 1; e->Ch[i + 1] = cfg->channels[i]; }
+    e->D = (cfg->num_freqs / 16 + 1) * cfg->channels[L - 1];
+    auto bail = [&](int code, const char *msg) { g_create_error = msg; delete e; return code; };
+    if (e->D != e->F[L] * cfg->channels[L - 1]) return bail(SE_ERR_ARG, "num_freqs/num_levels combination breaks the reference reshape (CRN.py:450,478)");
+    if (e->T <= 2 * (1 << (L - 1))) return bail(SE_ERR_ARG, "segment shorter than the largest dilation history (CRN.py:333)");
+    e->plan.N = cfg->n_fft;
+    e->plan.npass = fft_plan(cfg->n_fft / 2, e->plan.radices);
+    if (!e->plan.npass || e->plan.npass > kMaxRadices) return bail(SE_ERR_ARG, "n_fft must factor into 2s and 5s");
+    if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
+    if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
+    // tables: hamming(win) centred in n_fft (torch.stft), twiddles, overlap-add envelope
+    const int N = e->N, T = e->T, hop = cfg->hop, K = e->K;
+    std::vector<float> win(N, 0.0f), tw(2 * (size_t)N), env(K, 0.0f);
+    const int left = (N - cfg->win) / 2;
+    for (int i = 0; i < cfg->win; i++) win[left + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / cfg->win));
+    for (int i = 0; i < N; i++) { tw[2 * i] = (float)cos(2.0 * M_PI * i / N); tw[2 * i + 1] = (float)-sin(2.0 * M_PI * i / N); }
+    for (int i = 0; i < K; i++) {
+        const int pos = N / 2 + i;
+        float s = 0;
+        for (int t = 0; t < T; t++) { const int n = pos - t * hop; if (n >= 0 && n < N) s += win[n] * win[n]; }
+        env[i] = s;
+    }
+    int rc;
+    if ((rc = dev_upload(e, e->window, win)) || (rc = dev_upload(e, e->tw, tw)) || (rc = dev_upload(e, e->env, env))) {
+        g_create_error = e->err; delete e; return rc;
+    }
+    // opt in to large dynamic LDS for the FFT kernels
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes(K, N));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)istft_lds_bytes(T, N));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = e;
+    return SE_OK;
+}
+
+void se_destroy(se_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
+                         &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
+    for (DevBuf *b : singles) dev_free(*b);
+    for (int i = 0; i < 4; i++) {
+        dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]);
+        dev_free(e->hbuf[i][0]); dev_free(e->hbuf[i][1]);
+    }
+    for (int i = 0; i < SE_MAX_LEVELS; i++) {
+        Level &l = e->lv[i];
+        for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip}) { dev_free(p->w); dev_free(p->bias); }
+        for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
+        dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
+        dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
+    }
+    delete e;
+}
+
+int se_load_param(se_engine *e, const char *key, const float *host_data, const int64_t *shape, int ndim) {
+    if (!e || !key || !host_data) return fail(e, SE_ERR_ARG, "null argument");
+    const std::string k = canon(key);
+    // accept exactly the reference's key set
+    int idx = -1, n = 0;
+    char rest[64];
+    bool ok = false;
+    if (sscanf(k.c_str(), "convlist.%d.%63s", &idx, rest) == 2)
+        ok = idx >= 0 && idx < e->L && (!strcmp(rest, "conv.weight") || !strcmp(rest, "conv.bias") || !strcmp(rest, "norm.weight") || !strcmp(rest, "norm.bias"));
+    else if (sscanf(k.c_str(), "deconvlist.%d.%63s", &idx, rest) == 2) {
+        static const char *names[] = {"conv.weight", "conv.bias", "norm.weight", "norm.bias", "residualmask.weight", "residualmask.bias",
+                                      "residualnorm.weight", "residualnorm.bias", "residual.weight", "residual.bias"};
+        for (const char *nm : names) ok = ok || !strcmp(rest, nm);
+        ok = ok && idx >= 0 && idx < e->L;
+    } else if (sscanf(k.c_str(), "gru.sequence_model.%63[a-z_]%d%n", rest, &idx, &n) == 2)
+        ok = idx >= 0 && idx < e->NL && (size_t)n == k.size() &&
+             (!strcmp(rest, "weight_ih_l") || !strcmp(rest, "weight_hh_l") || !strcmp(rest, "bias_ih_l") || !strcmp(rest, "bias_hh_l"));
+    else
+        ok = k == "gru.fc_output_layer.weight" || k == "gru.fc_output_layer.bias" || k == "gru.norm.weight" || k == "gru.norm.bias";
+    if (!ok) return fail(e, SE_ERR_KEY, "unknown parameter key %s", key);
+    size_t cnt = 1;
+    std::vector<int64_t> shp;
+    for (int i = 0; i < ndim; i++) { if (shape[i] < 0) return fail(e, SE_ERR_SHAPE, "negative dimension in %s", key); cnt *= (size_t)shape[i]; shp.push_back(shape[i]); }
+    e->params[k].assign(host_data, host_data + cnt);
+    e->shapes[k] = shp;
+    e->weights_ready = false;
+    return SE_OK;
+}
+
+int se_reset(se_engine *e, int batch) {
+    if (!e || batch <= 0) return fail(e, SE_ERR_ARG, "batch must be positive");
+    int rc = ensure_ready(e);
+    if (rc) return rc;
+    const int L = e->L, T = e->T, B = batch, H = e->H, D = e->D, F0 = e->F[0];
+    e->B = B;
+    size_t spec_n = (size_t)B * e->M * T * F0 * 2;
+    if ((rc = dev_alloc(e, e->spec, spec_n)) || (rc = dev_alloc(e, e->maskspec, (size_t)B * T * F0 * 2))) return rc;
+    for (int i = 0; i < L; i++) {
+        const size_t nin = (size_t)B * e->Ch[i] * T * e->F[i];
+        for (int p = 0; p < 2; p++) {
+            if ((rc = dev_alloc(e, e->xin[i][p], nin))) return rc;
+            HIPCHECK(e, hipMemset(e->xin[i][p].p, 0, nin * sizeof(float)));
+        }
+        if ((rc = dev_alloc(e, e->enc_raw[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
+        const int lvl = L - 1 - i;  // decoder index i
+        const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fo = 2 * e->F[lvl + 1] - 1, Fr = e->F[lvl];
+        if ((rc = dev_alloc(e, e->dec_raw[i], (size_t)B * Co * T * Fo))) return rc;
+        if (lvl > 0) {
+            if ((rc = dev_alloc(e, e->dec_uv[i], (size_t)B * 2 * Co * T * Fr))) return rc;
+            if ((rc = dev_alloc(e, e->dec_out[i], (size_t)B * Co * T * Fr))) return rc;
+        }
+    }
+    if ((rc = dev_alloc(e, e->gru_in, (size_t)B * T * D)) || (rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
+        (rc = dev_alloc(e, e->seq[0], (size_t)B * T * H)) || (rc = dev_alloc(e, e->seq[1], (size_t)B * T * H)) ||
+        (rc = dev_alloc(e, e->fc_out, (size_t)B * T * D)) || (rc = dev_alloc(e, e->dec_in, (size_t)B * T * D)))
+        return rc;
+    for (int l = 0; l < e->NL; l++)
+        for (int p = 0; p < 2; p++) {
+            if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
+            HIPCHECK(e, hipMemset(e->hbuf[l][p].p, 0, (size_t)B * H * sizeof(float)));
+        }
+    for (int l = 0; l < 4; l++) e->hcur[l] = 0;
+    e->parity = 0;
+    HIPCHECK(e, hipDeviceSynchronize());
+    return SE_OK;
+}
+
+int se_forward(se_engine *e, const float *x, float *y, void *stream) {
+    if (!e || !x || !y) return fail(e, SE_ERR_ARG, "null argument");
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "se_forward before se_reset");
+    int rc = ensure_ready(e);
+    if (rc) return rc;
+    const long F = e->F[0], T = e->T, M = e->M;
+    return forward_dev(e, reinterpret_cast<const cf2 *>(x), M * F * T, F * T, 1, T, reinterpret_cast<cf2 *>(y), F * T, 1, T,
+                       static_cast<hipStream_t>(stream));
+}
+
+int se_stft(se_engine *e, const float *seg, int n, float *spec, void *stream) {
+    if (!e || !seg || !spec || n <= 0) return fail(e, SE_ERR_ARG, "bad argument");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const long F = e->F[0], T = e->T;
+    return launch_stft(e, seg, e->K, 0, 1, 0, e->K, n, reinterpret_cast<cf2 *>(spec), F * T, 1, T, static_cast<hipStream_t>(stream));
+}
+
+int se_istft(se_engine *e, const float *spec, int n, float *wav, void *stream) {
+    if (!e || !spec || !wav || n <= 0) return fail(e, SE_ERR_ARG, "bad argument");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const long F = e->F[0], T = e->T;
+    return launch_istft(e, reinterpret_cast<const cf2 *>(spec), F * T, 1, T, n, wav, e->K, static_cast<hipStream_t>(stream));
+}
+
+static int step_dev(se_engine *e, const float *src, long strideB, long strideM, long off, long Lsrc, float *wav_out, long wav_ld, hipStream_t st) {
+    const long F = e->F[0], T = e->T, M = e->M;
+    int rc;
+    cf2 *spec = reinterpret_cast<cf2 *>(e->spec.p);
+    cf2 *ms = reinterpret_cast<cf2 *>(e->maskspec.p);
+    if ((rc = launch_stft(e, src, strideB, strideM, (int)M, off, Lsrc, e->B * (int)M, spec, T * F, F, 1, st))) return rc;
+    if ((rc = forward_dev(e, spec, M * T * F, T * F, F, 1, ms, T * F, F, 1, st))) return rc;
+    return launch_istft(e, ms, T * F, F, 1, e->B, wav_out, wav_ld, st);
+}
+
+int se_step(se_engine *e, const float *wav_in, float *wav_out, void *stream) {
+    if (!e || !wav_in || !wav_out) return fail(e, SE_ERR_ARG, "null argument");
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "se_step before se_reset");
+    int rc = ensure_ready(e);
+    if (rc) return rc;
+    return step_dev(e, wav_in, (long)e->M * e->K, e->K, 0, e->K, wav_out, e->K, static_cast<hipStream_t>(stream));
+}
+
+int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t length, int flag, float *out, void *stream) {
+    if (!e || !mixture || !out || batch <= 0 || length <= 0) return fail(e, SE_ERR_ARG, "bad argument");
+    int rc;
+    if (!flag) {
+        if ((rc = se_reset(e, batch))) return rc;  // CRN.py:574-575
+    } else {
+        if (e->B != batch) return fail(e, SE_ERR_STATE, "flag=True with batch %d but the carried state holds %d streams", batch, e->B);
+        if ((rc = ensure_ready(e))) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long K = e->K, P = K / 2;
+    const long lead = flag ? 0 : P;                      // CRN.py:568-570
+    const long Lp = length + lead;
+    const long gap = K - (P + Lp % K) % K;               // utility.py:327-329
+    const long Nseg = 2 * (Lp + gap + P) / K;            // utility.py:360-368
+    if ((rc = dev_alloc(e, e->yseg, (size_t)batch * Nseg * K))) return rc;
+    for (long n = 0; n < Nseg; n++) {
+        // segment n covers padded[n*P, n*P+K) with padded = [0]*P | [0]*lead | x | zeros
+        const long off = n * P - P - lead;
+        // yseg is [B][Nseg][K]: the iSTFT writes segment n of every stream with row stride Nseg*K
+        if ((rc = step_dev(e, mixture, (long)e->M * length, length, off, length, e->yseg.p + n * K, Nseg * K, st))) return rc;
+    }
+    const long skip = lead;  // CRN.py:587-588
+    hipLaunchKernelGGL(k_overlap_avg, dim3((unsigned)((length + 255) / 256), batch), dim3(256), 0, st, e->yseg.p, out, (int)Nseg, (int)K,
+                       (long)length, skip);
+    HIPCHECK(e, hipGetLastError());
+    return SE_OK;
+}
+
+static int copy_out(se_engine *e, const float *dev, size_t n, float *host, int64_t cap, int64_t *count, hipStream_t st) {
+    if (count) *count = (int64_t)n;
+    if ((int64_t)n > cap) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+    HIPCHECK(e, hipStreamSynchronize(st));
+    HIPCHECK(e, hipMemcpy(host, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    return SE_OK;
+}
+
+int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream) {
+    if (!e || !name || !host_out) return fail(e, SE_ERR_ARG, "null argument");
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "no forward has run");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int L = e->L, T = e->T, B = e->B, cur = e->parity;
+    const float *src = nullptr;
+    int C = 0, F = 0, idx = -1;
+    bool gru_layout = false;
+    if (!strcmp(name, "feat")) { src = e->xin[0][cur].p; C = e->Ch[0]; F = e->F[0]; }
+    else if (!strcmp(name, "gru")) { src = e->dec_in.p; C = e->Ch[L]; F = e->F[L]; }
+    else if (sscanf(name, "enc%d", &idx) == 1 && idx >= 0 && idx < L) {
+        C = e->Ch[idx + 1]; F = e->F[idx + 1];
+        if (idx + 1 < L) src = e->xin[idx + 1][cur].p;
+        else { src = e->gru_in.p; gru_layout = true; }
+    } else if (sscanf(name, "dec%d", &idx) == 1 && idx >= 0 && idx < L - 1) {
+        const int lvl = L - 1 - idx;
+        src = e->dec_out[idx].p; C = e->Ch[lvl]; F = e->F[lvl];
+    } else return fail(e, SE_ERR_KEY, "unknown tap %s", name);
+    const size_t n = (size_t)B * C * T * F;
+    if (count) *count = (int64_t)n;
+    if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+    std::vector<float> h(n);
+    HIPCHECK(e, hipStreamSynchronize(st));
+    HIPCHECK(e, hipMemcpy(h.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int t = 0; t < T; t++)
+                for (int f = 0; f < F; f++) {
+                    const size_t si = gru_layout ? (((size_t)b * T + t) * C + c) * F + f : (((size_t)b * C + c) * T + t) * F + f;
+                    host_out[(((size_t)b * C + c) * F + f) * T + t] = h[si];
+                }
+    return SE_OK;
+}
+
+int se_export_state(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream) {
+    if (!e || !name || !host_out) return fail(e, SE_ERR_ARG, "null argument");
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "no state: call se_reset first");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = e->B, T = e->T, H = e->H;
+    int idx = -1;
+    if (!strcmp(name, "h")) {
+        const size_t n = (size_t)e->NL * B * H;
+        if (count) *count = (int64_t)n;
+        if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+        HIPCHECK(e, hipStreamSynchronize(st));
+        for (int l = 0; l < e->NL; l++)
+            HIPCHECK(e, hipMemcpy(host_out + (size_t)l * B * H, e->hbuf[l][e->hcur[l]].p, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost));
+        return SE_OK;
+    }
+    if (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L) {
+        const int C = e->Ch[idx], F = e->F[idx], P = 2 << idx;
+        const size_t n = (size_t)B * C * F * P, nsrc = (size_t)B * C * T * F;
+        if (count) *count = (int64_t)n;
+        if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+        std::vector<float> h(nsrc);
+        HIPCHECK(e, hipStreamSynchronize(st));
+        HIPCHECK(e, hipMemcpy(h.data(), e->xin[idx][e->parity].p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t bc = 0; bc < (size_t)B * C; bc++)
+            for (int f = 0; f < F; f++)
+                for (int p = 0; p < P; p++) host_out[(bc * F + f) * P + p] = h[(bc * T + (T - P + p)) * F + f];
+        return SE_OK;
+    }
+    return fail(e, SE_ERR_KEY, "unknown state %s", name);
+}
+
+int se_import_state(se_engine *e, const char *name, const float *host_in, int64_t count, void *stream) {
+    if (!e || !name || !host_in) return fail(e, SE_ERR_ARG, "null argument");
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "no state: call se_reset first");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = e->B, T = e->T, H = e->H;
+    int idx = -1;
+    HIPCHECK(e, hipStreamSynchronize(st));
+    if (!strcmp(name, "h")) {
+        if (count != (int64_t)e->NL * B * H) return fail(e, SE_ERR_SHAPE, "state h needs %d floats", e->NL * B * H);
+        for (int l = 0; l < e->NL; l++)
+            HIPCHECK(e, hipMemcpy(e->hbuf[l][e->hcur[l]].p, host_in + (size_t)l * B * H, (size_t)B * H * sizeof(float), hipMemcpyHostToDevice));
+        return SE_OK;
+    }
+    if (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L) {
+        const int C = e->Ch[idx], F = e->F[idx], P = 2 << idx;
+        if (count != (int64_t)B * C * F * P) return fail(e, SE_ERR_SHAPE, "state %s needs %ld floats", name, (long)B * C * F * P);
+        const size_t nsrc = (size_t)B * C * T * F;
+        std::vector<float> h(nsrc, 0.0f);
+        for (size_t bc = 0; bc < (size_t)B * C; bc++)
+            for (int f = 0; f < F; f++)
+                for (int p = 0; p < P; p++) h[(bc * T + (T - P + p)) * F + f] = host_in[(bc * F + f) * P + p];
+        HIPCHECK(e, hipMemcpy(e->xin[idx][e->parity].p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
+        return SE_OK;
+    }
+    return fail(e, SE_ERR_KEY, "unknown state %s", name);
+}
+
+double se_flops_per_frame(const se_engine *e) {
+    if (!e) return 0;
+    const int L = e->L, T = e->T, H = e->H, D = e->D;
+    double mac = 0;
+    for (int i = 0; i < L; i++) mac += (double)e->Ch[i + 1] * e->Ch[i] * 15 * e->F[i + 1] * T;
+    for (int j = 0; j < L; j++) {
+        const int lvl = L - 1 - j, Ci = e->Ch[lvl + 1], Co = lvl == 0 ? 2 : e->Ch[lvl];
+        mac += (double)Ci * Co * 15 * e->F[lvl + 1] * T;
+        if (lvl > 0) mac += 2.0 * Co * Co * e->F[lvl] * T;
+    }
+    for (int l = 0; l < e->NL; l++) mac += (double)T * (3.0 * H * (l == 0 ? D : H) + 3.0 * H * H);
+    mac += (double)T * D * H;
+    return 2.0 * mac;
+}
+
+int se_frames_per_segment(const se_engine *e) { return e ? e->T : 0; }
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""ctypes binding of the C ABI in include/se_engine.h (libse_engine.so, HIP / gfx950).
+
+This is the reference-side stub a maintainer would add: it carries no arithmetic, only
+pointer plumbing.  PyTorch is used for device memory and streams; the signatures themselves are plain C.
+There is no CPU fallback: if the library or a GPU is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libse_engine.so")
+SE_MAX_LEVELS = 8
+
+EXPORTS = [
+    "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_step",
+    "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
+    "se_import_state", "se_flops_per_frame", "se_frames_per_segment",
+]
+
+
+class SeConfig(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("channels", C.c_int32 * SE_MAX_LEVELS), ("num_freqs", C.c_int32),
+                ("hidden", C.c_int32), ("num_layers", C.c_int32), ("num_inputs", C.c_int32),
+                ("kernel_size", C.c_int32), ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32),
+                ("segment_length", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libse_engine.so; raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C speech_enhancement_mi_amd/csrc).  The engine has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, i64p = C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
+    L.se_abi_version.restype = C.c_int
+    L.se_create.argtypes = [C.POINTER(SeConfig), C.c_int, C.POINTER(vp)]
+    L.se_destroy.argtypes = [vp]
+    L.se_destroy.restype = None
+    L.se_last_error.argtypes = [vp]
+    L.se_last_error.restype = C.c_char_p
+    L.se_load_param.argtypes = [vp, C.c_char_p, fp, i64p, C.c_int]
+    L.se_reset.argtypes = [vp, C.c_int]
+    L.se_step.argtypes = [vp, fp, fp, vp]
+    L.se_realtime_process.argtypes = [vp, fp, C.c_int, C.c_int64, C.c_int, fp, vp]
+    L.se_stft.argtypes = [vp, fp, C.c_int, fp, vp]
+    L.se_istft.argtypes = [vp, fp, C.c_int, fp, vp]
+    L.se_forward.argtypes = [vp, fp, fp, vp]
+    L.se_read_tap.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
+    L.se_export_state.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
+    L.se_import_state.argtypes = [vp, C.c_char_p, fp, C.c_int64, vp]
+    L.se_flops_per_frame.argtypes = [vp]
+    L.se_flops_per_frame.restype = C.c_double
+    L.se_frames_per_segment.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def make_config(num_channels, num_freqs, hidden, segment_length, num_layers=1, num_inputs=3, kernel_size=3,
+                sample_rate=16000, win_length=25, hop_length=10, n_fft=400) -> SeConfig:
+    cfg = SeConfig()
+    if len(num_channels) > SE_MAX_LEVELS:
+        raise ValueError("too many levels")
+    cfg.num_levels = len(num_channels)
+    for i, c in enumerate(num_channels):
+        cfg.channels[i] = int(c)
+    cfg.num_freqs, cfg.hidden, cfg.num_layers = int(num_freqs), int(hidden), int(num_layers)
+    cfg.num_inputs, cfg.kernel_size, cfg.n_fft = int(num_inputs), int(kernel_size), int(n_fft)
+    cfg.win = int(round(sample_rate / 1000.0 * win_length))   # speechbrain STFT convention (CRN.py:421-425)
+    cfg.hop = int(round(sample_rate / 1000.0 * hop_length))
+    cfg.segment_length = int(segment_length)
+    return cfg
+
+
+class Engine:
+    """Thin RAII wrapper over one se_engine handle.  All tensor arguments are CUDA(HIP) torch tensors."""
+
+    def __init__(self, cfg: SeConfig, device: int = 0):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.se_create(C.byref(cfg), self.device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"se_create failed ({rc}): {self.lib.se_last_error(None).decode()}")
+        self._h = h
+        self.T = self.lib.se_frames_per_segment(h)
+        self.F, self.M, self.K = cfg.num_freqs, cfg.num_inputs, cfg.segment_length
+        self.batch = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.se_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"se_engine error {rc}: {self.lib.se_last_error(self._h).decode()}")
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _dev(t, shape=None):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("the engine takes contiguous float32 tensors on the GPU (no CPU fallback)")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+            shp = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            self._check(self.lib.se_load_param(self._h, k.encode(), C.c_void_p(a.ctypes.data), shp, a.ndim))
+
+    def reset(self, batch: int):
+        self._check(self.lib.se_reset(self._h, int(batch)))
+        self.batch = int(batch)
+
+    def step(self, wav_in, wav_out=None):
+        import torch
+        B = self.batch
+        if wav_out is None:
+            wav_out = torch.empty((B, self.K), dtype=torch.float32, device=wav_in.device)
+        self._check(self.lib.se_step(self._h, self._dev(wav_in, (B, self.M, self.K)), self._dev(wav_out, (B, self.K)), self._stream()))
+        return wav_out
+
+    def realtime_process(self, mixture, flag=False, out=None):
+        import torch
+        B, M, L = mixture.shape
+        if M != self.M:
+            raise RuntimeError(f"expected {self.M} microphones, got {M}")
+        if out is None:
+            out = torch.empty((B, L), dtype=torch.float32, device=mixture.device)
+        self._check(self.lib.se_realtime_process(self._h, self._dev(mixture), B, L, int(bool(flag)), self._dev(out, (B, L)), self._stream()))
+        self.batch = B
+        return out
+
+    def stft(self, seg):
+        import torch
+        n = seg.shape[0]
+        spec = torch.empty((n, self.F, self.T, 2), dtype=torch.float32, device=seg.device)
+        self._check(self.lib.se_stft(self._h, self._dev(seg, (n, self.K)), n, self._dev(spec), self._stream()))
+        return spec
+
+    def istft(self, spec):
+        import torch
+        n = spec.shape[0]
+        wav = torch.empty((n, self.K), dtype=torch.float32, device=spec.device)
+        self._check(self.lib.se_istft(self._h, self._dev(spec, (n, self.F, self.T, 2)), n, self._dev(wav), self._stream()))
+        return wav
+
+    def forward(self, x):
+        import torch
+        B = self.batch
+        y = torch.empty((B, self.F, self.T, 2), dtype=torch.float32, device=x.device)
+        self._check(self.lib.se_forward(self._h, self._dev(x, (B, self.M, self.F, self.T, 2)), self._dev(y), self._stream()))
+        return y
+
+    def _host_read(self, fn, name: str) -> np.ndarray:
+        n = C.c_int64(0)
+        probe = np.empty(1, np.float32)
+        fn(self._h, name.encode(), C.c_void_p(probe.ctypes.data), 0, C.byref(n), self._stream())
+        if n.value <= 0:
+            self._check(-1)
+        out = np.empty(n.value, np.float32)
+        self._check(fn(self._h, name.encode(), C.c_void_p(out.ctypes.data), n.value, C.byref(n), self._stream()))
+        return out
+
+    def read_tap(self, name: str) -> np.ndarray:
+        return self._host_read(self.lib.se_read_tap, name)
+
+    def export_state(self, name: str) -> np.ndarray:
+        return self._host_read(self.lib.se_export_state, name)
+
+    def import_state(self, name: str, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._check(self.lib.se_import_state(self._h, name.encode(), C.c_void_p(a.ctypes.data), a.size, self._stream()))
+
+    @property
+    def flops_per_frame(self) -> float:
+        return float(self.lib.se_flops_per_frame(self._h))
