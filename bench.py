@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: streaming frames/s of TemporalCRN.realtime_process at batch 256 on MI355X.
+
+A "step" is one realtime_process call (the hot path) over one batch of B synthetic 3 s, 16 kHz,
+3-microphone utterances already resident in HBM: B x Nseg frames (Nseg = 34 windows of 3200 samples per stream,
+including the reference's K/2 left pad and gap padding).  value = frames / s summed over all ranks.
+N > 1: one process per GPU, streams sharded across ranks (independent units: no data-path collective, weak
+scaling); barrier + synchronize on both sides of the timed region, MAX over ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream in an extra
+profiled step after the timed region) and `cpu_baseline` (the C oracle timed on the host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 dense peak
+
+
+def crn_cfg(nfft):
+    return dict(num_channels=[16, 32, 64, 128], num_freqs=nfft // 2 + 1, hidden=512, segment_length=3200, num_layers=2,
+                num_inputs=3, kernel_size=3, sample_rate=16000, win_length=25, hop_length=10, n_fft=nfft)
+
+
+def cpu_baseline(cfg, sd, seconds_budget=20.0):
+    """Oracle (C restatement of the reference path, OpenMP) on the host cores, bounded sample."""
+    from oracle import crn_oracle as orc
+    from speech_enhancement_mi_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    o = orc.CrnOracle(**cfg)
+    o.load_state_dict(sd)
+    B, L = max(2, min(cores, 32)), 8000
+    mix, _ = synth.synth_utterances(B, L, 3, seed=99)
+    P, K = 1600, 3200
+    Lp = L + P
+    gap = K - (P + Lp % K) % K
+    nseg = 2 * (Lp + gap + P) // K
+    o.realtime_process(mix[:1, :, :3200])  # warm
+    reps, t0 = 0, time.time()
+    while True:
+        o.realtime_process(mix)
+        reps += 1
+        if time.time() - t0 > seconds_budget / 2 or reps >= 8:
+            break
+    dt = time.time() - t0
+    return dict(value=B * nseg * reps / dt, unit="frames/s", cores=cores, kind="port",
+                sample=f"{reps} x realtime_process of {B} streams x {L} samples ({nseg} frames each), C oracle with OpenMP")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--nfft", type=int, default=512, help="512 = BASELINE.json configs[1]; 400 = reference config.yaml default")
+    ap.add_argument("--seconds", type=float, default=3.0, help="utterance length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from speech_enhancement_mi_amd import engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = crn_cfg(args.nfft)
+    spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3)
+    sd = synth.make_state_dict(spec, seed=0)
+    eng = engine.Engine(engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], 3200, 2, 3, 3, 16000, 25, 10, args.nfft), local_rank)
+    eng.load_state_dict(sd)
+
+    B, L = args.batch, int(args.seconds * 16000)
+    base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)  # 16 distinct utterances, tiled over the batch
+    mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
+    out = torch.empty((B, L), dtype=torch.float32, device="cuda")
+    P, K = 1600, 3200
+    Lp = L + P
+    gap = K - (P + Lp % K) % K
+    nseg = 2 * (Lp + gap + P) // K
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.realtime_process(mix, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.realtime_process(mix, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all()), "non-finite output"
+
+    frames = world * B * nseg * args.steps
+    value = frames / dt
+
+    # ---- roofline leg: one extra profiled step, HIP events around every launch on the launch stream ----
+    eng.profile(True)
+    eng.realtime_process(mix, out=out)
+    recs = eng.profile_read()
+    eng.profile(False)
+    by_kernel = {}
+    for r in recs:
+        k = by_kernel.setdefault(r["kernel"], dict(ms=0.0, launches=0, flops=0.0))
+        k["ms"] += r["ms"]
+        k["launches"] += r["launches"]
+        k["flops"] += r["flops_per_launch"] * r["launches"]
+    dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+    d = by_kernel[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
+                    avg_launch_us=1e3 * d["ms"] / max(1, d["launches"]), launches_per_step=d["launches"],
+                    flops_per_launch=d["flops"] / max(1, d["launches"]),
+                    whole_path_tflops=value / world * eng.flops_per_frame / 1e12,
+                    kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                                     tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0))
+                             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
+                    labels={r["label"]: dict(ms=round(r["ms"], 3), launches=r["launches"]) for r in recs})
+
+    result = dict(metric="streaming frames/sec @ b256 (CRN, 3200-samp 16 kHz)", value=value, unit="frames/s",
+                  n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+                  higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                  config=dict(workload=f"TemporalCRN realtime_process, batch {B} streams/GPU, {args.nfft}-pt STFT / {cfg['num_freqs']} bins, hop 160, "
+                                       f"{args.seconds:g} s utterances ({nseg} frames of 3200 samples per stream), hash-generated weights",
+                              streams_per_gpu=B, frames_per_stream=nseg, n_fft=args.nfft, parallelism=f"streams sharded x{world}, no collective",
+                              realtime_factor=value * 0.1, mflop_per_frame=eng.flops_per_frame / 1e6),
+                  roofline=roofline)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, sd)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

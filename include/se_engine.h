@@ -97,7 +97,14 @@ int se_import_state(se_engine *e, const char *name, const float *host_in, int64_
 double se_flops_per_frame(const se_engine *e);
 int se_frames_per_segment(const se_engine *e); /* T */
 
-/* Names and launch counts of the kernels one se_step enqueues (for bench.py's roofline accounting). */
+/* Per-kernel timing for bench.py's roofline leg: with profiling enabled every kernel launch is bracketed by
+ * two HIP events on the launch stream.  se_profile(e, on) clears the counters; se_profile_read() folds the
+ * pending events (synchronises) and returns entry `index` (kernel function name, launch-site label, total
+ * milliseconds, launches, algorithmic FLOPs per launch); returns 1 past the last entry. */
+int se_profile(se_engine *e, int enable);
+int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap, double *ms_total,
+                    int64_t *launches, double *flops_per_launch);
+
 int se_abi_version(void);
 
 #ifdef __cplusplus

@@ -36,17 +36,78 @@ struct ConvArgs {
     int Ci, Co, CoPad, T, Fi, FP, Fy;
     int s, os, oo;       // input column = s*m + coloff ; output column = os*m + oo
     int colpad;          // patch column c holds input freq c - colpad
-    int tlo_off;         // patch row 0 holds source time ta + tlo_off
-    int rows_extra;      // patch rows = (tb - ta + 1) + rows_extra
+    int tlo_off;         // first row group holds source times ta + tlo_off + j
+    int ngroup, dil;     // time taps: row group g holds source times ta + tlo_off + g*dil + j, j in [0, tb-ta]
+    int grouped;         // 1: patch rows = ngroup * (tb-ta+1) (one block per time tap; wins when dil is large)
+                         // 0: patch rows = (tb-ta+1) + (ngroup-1)*dil (one contiguous time range)
     int ntap;
-    int rowoff[kMaxTaps];
+    int rowgrp[kMaxTaps];  // row group (time tap index) of each tap
     int coloff[kMaxTaps];
     int CC, nchunk, tiles_per_wg, St;
     int relu_lo, relu_hi;  // output channels in [relu_lo, relu_hi) get ReLU
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+// Stages one Cin-chunk of the input patch (zero halo, causal history from xprev) and of the weights.
+// Row bookkeeping (channel, time-tap group, row -> source pointer, LDS row, validity) is wave-uniform and kept
+// on the scalar unit (no per-element integer divisions); each lane only adds its column.  Loads are issued in
+// batches of 8 independent rows per wave before any LDS store, so ~8 global loads per lane are in flight.
+__device__ __forceinline__ void conv_stage(const ConvArgs &a, float *wl, float *patch, const float *xb, const float *xpb,
+                                           long xs_c, int ch, int RT, int R, int Sc, int ta, int wslab, int tid) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CC = a.CC, St = a.St, ci0 = ch * CC;
+    const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
+    constexpr int U = 8;
+    for (int col0 = 0; col0 < St; col0 += 64) {
+        const int col = col0 + lane;
+        const int fi = col - a.colpad;
+        const bool col_ok = col < St;
+        const bool f_ok = col_ok && fi >= 0 && fi < a.Fi;
+        const int fic = min(max(fi, 0), a.Fi - 1);
+        int c = 0, g = 0, j = wave;  // this wave's row cursor (rows wave, wave+4, ... of the [CC][NGp][RTp] patch)
+        while (c < CC) {
+            float v[U];
+            int ldsrow[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                while (j >= RTp) { j -= RTp; if (++g == NGp) { g = 0; c++; } }
+                const bool row_in = c < CC;
+                const int cc_ = row_in ? c : CC - 1;
+                const int ts = ta + a.tlo_off + g * a.dil + j;
+                const bool hist = ts < 0;
+                const float *base = (hist && xpb) ? xpb : xb;
+                const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1);
+                const int ci = min(ci0 + cc_, a.Ci - 1);
+                const bool row_ok = row_in && (ci0 + cc_ < a.Ci) && (hist ? (xpb != nullptr && ts + a.T >= 0) : ts < a.T);
+                const float x = base[ci * xs_c + (long)tsc * a.Fi + fic];
+                v[u] = (row_ok && f_ok) ? x : 0.0f;
+                ldsrow[u] = row_in ? cc_ * Sc + (g * RTp + j) * St : -1;
+                j += 4;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (ldsrow[u] >= 0 && col_ok) patch[ldsrow[u] + col] = v[u];
+        }
+    }
+    const float4 *wsrc = reinterpret_cast<const float4 *>(a.w + (long)ch * wslab);
+    float4 *wdst = reinterpret_cast<float4 *>(wl);
+    const int n4 = wslab >> 2;
+    for (int i0 = tid; i0 < n4; i0 += 256 * 4) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = wsrc[min(i0 + u * 256, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u * 256 < n4) wdst[i0 + u * 256] = q[u];
+    }
+}
+
+// NTAP = number of taps of this tap set (15 encoder, 9 / 6 transposed even / odd, 1 for 1x1): a template
+// parameter so the tap loop unrolls and the per-tap LDS offsets live in SGPRs; NT = column tiles per wave.
+// The MFMA loop is branch-free: column tiles beyond the workgroup's range read a clamped address and
+// their accumulators are simply never stored.
+template <int NTAP, int NT>
+__global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
@@ -54,82 +115,87 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     const int p0 = blockIdx.x * a.tiles_per_wg * 32;
     if (p0 >= P) return;
     const int p1 = min(P, p0 + a.tiles_per_wg * 32);
-    const int ntile = (p1 - p0 + 31) >> 5;
     const int ta = p0 / a.FP, tb = (p1 - 1) / a.FP;
-    const int R = tb - ta + 1 + a.rows_extra;
+    const int RT = tb - ta + 1;
+    const int R = a.grouped ? a.ngroup * RT : RT + (a.ngroup - 1) * a.dil;
     const int St = a.St, Sc = R * St;
     const int CC = a.CC, CoPad = a.CoPad;
-    float *wl = lds;                            // [ntap][CC][CoPad]  (first: keeps 16-B alignment for float4 copies)
-    float *patch = lds + a.ntap * CC * CoPad;   // [CC][R][St]
+    float *wl = lds;                          // [NTAP][CC][CoPad]  (first: keeps 16-B alignment for float4 copies)
+    float *patch = lds + NTAP * CC * CoPad;   // [CC][R][St]
     const int MT = CoPad >> 5, NCG = 4 / MT;
     const int mt = wave % MT, cg = wave / MT;
     const int half = lane >> 5, l31 = lane & 31;
 
     int lane_base[NT], pos_t[NT], pos_m[NT];
-    bool tile_ok[NT], lane_ok[NT];
+    bool lane_ok[NT];
 #pragma unroll
     for (int i = 0; i < NT; i++) {
-        const int tile = cg + i * NCG;
-        tile_ok[i] = tile < ntile;
-        const int p = p0 + tile * 32 + l31;
-        lane_ok[i] = tile_ok[i] && p < p1;
+        const int p = p0 + (cg + i * NCG) * 32 + l31;
+        lane_ok[i] = p < p1;
         const int pc = lane_ok[i] ? p : (p1 - 1);
         const int t = pc / a.FP, m = pc - t * a.FP;
         pos_t[i] = t;
         pos_m[i] = m;
         lane_base[i] = (t - ta) * St + a.s * m + half * Sc;
     }
+    int toff[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) toff[t] = a.rowgrp[t] * (a.grouped ? RT : a.dil) * St + a.coloff[t];
+
     f32x16 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
 
-    const int tlo = ta + a.tlo_off;
     const long xs_c = (long)a.T * a.Fi;  // channel stride in x
     const float *xb = a.x + (long)b * a.Ci * xs_c;
     const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : nullptr;
-    const int wslab = a.ntap * CC * CoPad;
+    const int wslab = NTAP * CC * CoPad;
+    const int hk = CC >> 1;
 
     for (int ch = 0; ch < a.nchunk; ch++) {
-        const int ci0 = ch * CC;
         __syncthreads();  // previous chunk fully consumed
-        // ---- stage input patch (zero halo, causal history from xprev) ----
-        for (int rid = wave; rid < CC * R; rid += 4) {
-            const int c = rid / R, r = rid - c * R;
-            const int ci = ci0 + c, ts = tlo + r;
-            const float *srow = nullptr;
-            if (ci < a.Ci) {
-                if (ts >= 0 && ts < a.T) srow = xb + ci * xs_c + (long)ts * a.Fi;
-                else if (ts < 0 && xpb && ts + a.T >= 0) srow = xpb + ci * xs_c + (long)(ts + a.T) * a.Fi;
-            }
-            float *drow = patch + c * Sc + r * St;
-            for (int col = lane; col < St; col += 64) {
-                const int fi = col - a.colpad;
-                drow[col] = (srow && fi >= 0 && fi < a.Fi) ? srow[fi] : 0.0f;
-            }
-        }
-        // ---- stage weight slab (contiguous copy) ----
-        {
-            const float4 *wsrc = reinterpret_cast<const float4 *>(a.w + (long)ch * wslab);
-            float4 *wdst = reinterpret_cast<float4 *>(wl);
-            for (int i = tid; i < (wslab >> 2); i += 256) wdst[i] = wsrc[i];
-        }
+        conv_stage(a, wl, patch, xb, xpb, xs_c, ch, RT, R, Sc, ta, wslab, tid);
         __syncthreads();
-        // ---- MFMA over taps x channel pairs ----
-        for (int tap = 0; tap < a.ntap; tap++) {
-            const int toff = a.rowoff[tap] * St + a.coloff[tap];
-            const float *wt = wl + tap * CC * CoPad + mt * 32 + l31 + half * CoPad;
-            for (int kp = 0; kp < (CC >> 1); kp++) {
-                const float av = wt[kp * 2 * CoPad];
-                const int boff = toff + kp * 2 * Sc;
+        // software pipeline, one (tap, channel pair) step deep: the LDS reads of step s+1 are issued before
+        // the NT MFMAs of step s (256 matrix-pipe cycles cover the ~100-cycle LDS latency).
+        int wofs = mt * 32 + l31 + half * CoPad;  // A fragment offset inside wl (floats)
+        int lb[NT];
 #pragma unroll
-                for (int i = 0; i < NT; i++) {
-                    if (tile_ok[i]) {
-                        const float bv = patch[lane_base[i] + boff];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
-                    }
+        for (int i = 0; i < NT; i++) lb[i] = lane_base[i];
+        float av = wl[wofs], bv[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) bv[i] = patch[lb[i] + toff[0]];
+        const int tapA = CC * CoPad;
+        for (int kp = 0; kp < hk; kp++) {
+            // opaque to the optimiser: keeps the 5*NTAP fragment addresses from being hoisted out of the loop
+            // (75 live address registers spill); one v_add per LDS read is free next to a 64-cycle MFMA.
+            asm volatile("" : "+v"(wofs));
+#pragma unroll
+            for (int i = 0; i < NT; i++) asm volatile("" : "+v"(lb[i]));
+            const int ka = kp * 2 * CoPad, kb = kp * 2 * Sc;
+            const int kpn = kp + 1 < hk ? kp + 1 : 0;  // last step prefetches a valid (unused) address
+            const int kan = kpn * 2 * CoPad, kbn = kpn * 2 * Sc;
+#pragma unroll
+            for (int tap = 0; tap < NTAP; tap++) {
+                float an, bn[NT];
+                if (tap + 1 < NTAP) {
+                    an = wl[wofs + ka + (tap + 1) * tapA];
+#pragma unroll
+                    for (int i = 0; i < NT; i++) bn[i] = patch[lb[i] + kb + toff[tap + 1]];
+                } else {
+                    an = wl[wofs + kan];
+#pragma unroll
+                    for (int i = 0; i < NT; i++) bn[i] = patch[lb[i] + kbn + toff[0]];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                av = an;
+#pragma unroll
+                for (int i = 0; i < NT; i++) bv[i] = bn[i];
             }
         }
     }
@@ -150,6 +216,64 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
             }
         }
     }
+}
+
+// Same tiling on the vector ALU for convolutions with <= 4 output channels (the last decoder block,
+// 16 -> 2 channels: a 32-row MFMA tile would be 94 % padding).  One thread per output position,
+// weights broadcast from LDS as float4 ([tap][ci][4]).
+template <int NTAP>
+__global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int P = a.T * a.FP;
+    const int p0 = blockIdx.x * a.tiles_per_wg * 32;
+    if (p0 >= P) return;
+    const int p1 = min(P, p0 + a.tiles_per_wg * 32);
+    const int ta = p0 / a.FP, tb = (p1 - 1) / a.FP;
+    const int RT = tb - ta + 1;
+    const int R = a.grouped ? a.ngroup * RT : RT + (a.ngroup - 1) * a.dil;
+    const int St = a.St, Sc = R * St, CC = a.CC;
+    float *wl = lds;                      // [NTAP][CC][4]
+    float *patch = lds + NTAP * CC * 4;   // [CC][R][St]
+    const int p = p0 + tid;
+    const bool ok = p < p1;
+    const int pc = ok ? p : (p1 - 1);
+    const int t = pc / a.FP, m = pc - t * a.FP;
+    const int base = (t - ta) * St + a.s * m;
+    int toff[NTAP];
+#pragma unroll
+    for (int k = 0; k < NTAP; k++) toff[k] = a.rowgrp[k] * (a.grouped ? RT : a.dil) * St + a.coloff[k];
+    float4 acc = make_float4(0, 0, 0, 0);
+    const long xs_c = (long)a.T * a.Fi;
+    const float *xb = a.x + (long)b * a.Ci * xs_c;
+    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : nullptr;
+    const int wslab = NTAP * CC * 4;
+    for (int ch = 0; ch < a.nchunk; ch++) {
+        __syncthreads();
+        conv_stage(a, wl, patch, xb, xpb, xs_c, ch, RT, R, Sc, ta, wslab, tid);
+        __syncthreads();
+        for (int c = 0; c < CC; c++) {
+            const float *pc_ = patch + c * Sc + base;
+#pragma unroll
+            for (int tap = 0; tap < NTAP; tap++) {
+                const float v = pc_[toff[tap]];
+                const float4 w = *reinterpret_cast<const float4 *>(wl + (tap * CC + c) * 4);
+                acc.x += w.x * v; acc.y += w.y * v; acc.z += w.z * v; acc.w += w.w * v;
+            }
+        }
+    }
+    if (!ok) return;
+    const long ys_c = (long)a.T * a.Fy;
+    float *yp = a.y + (long)b * a.Co * ys_c + (long)t * a.Fy + a.os * m + a.oo;
+    const float r4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int co = 0; co < 4; co++)
+        if (co < a.Co) {
+            float v = r4[co] + a.bias[co];
+            if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
+            yp[co * ys_c] = v;
+        }
 }
 
 }  // namespace se

@@ -24,28 +24,28 @@ struct GemmArgs {
     int relu;
 };
 
-__device__ inline void gemm_stage(float *dst, const float *src, long ld, int rows_valid, int row0, int k0, int K, int tid) {
-    // 128 rows x 32 k: 1024 float4 slots, 4 per thread
+// Stage 128 rows x 32 k of a K-contiguous operand into LDS (row stride kGemmLd).  Loads are unconditional
+// 16-B loads from clamped addresses (K % 4 == 0 is enforced by the host), out-of-range values are zeroed by
+// select, so the four loads of a thread are in flight together.
+__device__ __forceinline__ void gemm_stage(float *dst, const float *src, long ld, int rows_valid, int row0, int k0, int K, int tid) {
+    float4 q[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int slot = tid + it * 256;
         const int r = slot >> 3, kq = (slot & 7) * 4;
-        const int row = row0 + r, k = k0 + kq;
-        float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        if (row < rows_valid) {
-            const float *p = src + (long)row * ld + k;
-            if (k + 3 < K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                const float4 q = *reinterpret_cast<const float4 *>(p);
-                v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
-            } else {
-                if (k < K) v0 = p[0];
-                if (k + 1 < K) v1 = p[1];
-                if (k + 2 < K) v2 = p[2];
-                if (k + 3 < K) v3 = p[3];
-            }
-        }
+        const int row = min(row0 + r, rows_valid - 1), k = min(k0 + kq, K - 4);
+        q[it] = *reinterpret_cast<const float4 *>(src + (long)row * ld + k);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int slot = tid + it * 256;
+        const int r = slot >> 3, kq = (slot & 7) * 4;
+        const bool ok = (row0 + r < rows_valid) && (k0 + kq < K);
         float *d = dst + r * kGemmLd + kq;
-        d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+        d[0] = ok ? q[it].x : 0.0f;
+        d[1] = ok ? q[it].y : 0.0f;
+        d[2] = ok ? q[it].z : 0.0f;
+        d[3] = ok ? q[it].w : 0.0f;
     }
 }
 
@@ -131,51 +131,53 @@ __global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) {
     const int rt = wave & 1, kh = wave >> 1;
     const int l15 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32 + rt * 16;
-    const int H = a.H;
-    const int nkb = (H + 15) >> 4;
+    const int H = a.H;          // multiple of 16 (host-checked): every 16-deep k block is complete
+    const int nkb = H >> 4;
     const int kb0 = kh ? (nkb >> 1) : 0, kb1 = kh ? nkb : (nkb >> 1);
-    const int arow = r0 + l15;
-    const bool arow_ok = arow < a.B;
+    // out-of-range rows / hidden units read a clamped (valid) address; their results are never stored
+    const int arow = min(r0 + l15, a.B - 1);
     const int n = n0 + l15;
-    const bool n_ok = n < H;
-    const float *ap = a.hprev + (long)(arow_ok ? arow : 0) * H;
-    const float *bp0 = a.whh + (long)(n_ok ? n : 0) * H;
+    const int nc = min(n, H - 1);
+    const float *ap = a.hprev + (long)arow * H + kq * 4;
+    const float *bp0 = a.whh + (long)nc * H + kq * 4;
     const float *bp1 = bp0 + (long)H * H;
     const float *bp2 = bp1 + (long)H * H;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    const float4 zero4 = make_float4(0, 0, 0, 0);
-    auto ld4 = [&](const float *p, int k, bool ok) -> float4 {
-        if (!ok || k >= H) return zero4;
-        if (k + 3 < H) return *reinterpret_cast<const float4 *>(p + k);
-        float4 v = zero4;
-        v.x = p[k];
-        if (k + 1 < H) v.y = p[k + 1];
-        if (k + 2 < H) v.z = p[k + 2];
-        return v;
-    };
-    float4 av, b0, b1, b2;
-    if (kb0 < kb1) {
-        const int k = kb0 * 16 + kq * 4;
-        av = ld4(ap, k, arow_ok); b0 = ld4(bp0, k, n_ok); b1 = ld4(bp1, k, n_ok); b2 = ld4(bp2, k, n_ok);
+    constexpr int PF = 2;  // k blocks in flight
+    float4 qa[PF], q0[PF], q1[PF], q2[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int k = min(kb0 + i, nkb - 1) * 16;
+        qa[i] = *reinterpret_cast<const float4 *>(ap + k);
+        q0[i] = *reinterpret_cast<const float4 *>(bp0 + k);
+        q1[i] = *reinterpret_cast<const float4 *>(bp1 + k);
+        q2[i] = *reinterpret_cast<const float4 *>(bp2 + k);
     }
-    for (int kb = kb0; kb < kb1; kb++) {
-        const float4 ca = av, c0 = b0, c1 = b1, c2 = b2;
-        if (kb + 1 < kb1) {
-            const int k = (kb + 1) * 16 + kq * 4;
-            av = ld4(ap, k, arow_ok); b0 = ld4(bp0, k, n_ok); b1 = ld4(bp1, k, n_ok); b2 = ld4(bp2, k, n_ok);
+    for (int kb = kb0; kb < kb1; kb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const float4 ca = qa[i], c0 = q0[i], c1 = q1[i], c2 = q2[i];
+            const bool live = kb + i < kb1;  // uniform; a dead slot contributes nothing (halves of odd length)
+            const int k = min(kb + i + PF, nkb - 1) * 16;
+            qa[i] = *reinterpret_cast<const float4 *>(ap + k);
+            q0[i] = *reinterpret_cast<const float4 *>(bp0 + k);
+            q1[i] = *reinterpret_cast<const float4 *>(bp1 + k);
+            q2[i] = *reinterpret_cast<const float4 *>(bp2 + k);
+            const float s = live ? 1.0f : 0.0f;
+            const float ax = ca.x * s, ay = ca.y * s, az = ca.z * s, aw = ca.w * s;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, c0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, c1.x, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, c2.x, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, c0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, c1.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, c2.y, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az, c0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az, c1.z, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(az, c2.z, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, c0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, c1.w, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, c2.w, acc2, 0, 0, 0);
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c1.x, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, c2.x, acc2, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c1.y, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, c2.y, acc2, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c1.z, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, c2.z, acc2, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c1.w, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, c2.w, acc2, 0, 0, 0);
     }
     if (kh == 1) {
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) {
         }
     }
     __syncthreads();
-    if (kh == 0 && n_ok) {
+    if (kh == 0 && n < H) {
         const float bh_r = a.bhh[n], bh_z = a.bhh[H + n], bh_n = a.bhh[2 * H + n];
 #pragma unroll
         for (int r = 0; r < 4; r++) {

@@ -46,6 +46,7 @@ struct ConvPlan {
     size_t lds = 0;
     DevBuf w, bias;
     bool active = false;
+    double flops = 0;  // algorithmic FLOPs per stream per launch (SURVEY.md 8d accounting)
 };
 
 struct Level {  // one encoder/decoder level
@@ -86,6 +87,14 @@ struct se_engine {
     int hcur[4]{};
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
     DevBuf yseg, scratch;
+
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool prof_on = false;
+    struct ProfRec { int label; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    struct ProfLabel { std::string kernel, label; double flops; double ms = 0; long launches = 0; };
+    std::vector<ProfLabel> prof_labels;
 };
 
 namespace {
@@ -132,6 +141,33 @@ void dev_free(DevBuf &b) {
     b.n = 0;
 }
 
+int prof_label(se_engine *e, const char *kernel, const std::string &label, double flops) {
+    for (size_t i = 0; i < e->prof_labels.size(); i++)
+        if (e->prof_labels[i].label == label) { e->prof_labels[i].flops = flops; return (int)i; }
+    e->prof_labels.push_back({kernel, label, flops});
+    return (int)e->prof_labels.size() - 1;
+}
+
+struct ProfScope {  // brackets one launch with two events when profiling is on
+    se_engine *e;
+    hipStream_t st;
+    int idx = -1;
+    ProfScope(se_engine *e_, const char *kernel, const std::string &label, double flops, hipStream_t st_) : e(e_), st(st_) {
+        if (!e->prof_on) return;
+        hipEvent_t ev[2];
+        for (auto &x : ev) {
+            if (!e->prof_pool.empty()) { x = e->prof_pool.back(); e->prof_pool.pop_back(); }
+            else if (hipEventCreate(&x) != hipSuccess) return;
+        }
+        e->prof_recs.push_back({prof_label(e, kernel, label, flops), ev[0], ev[1]});
+        idx = (int)e->prof_recs.size() - 1;
+        (void)hipEventRecord(ev[0], st);
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(e->prof_recs[idx].b, st);
+    }
+};
+
 std::string canon(const char *key) {
     std::string k(key);
     size_t pos = k.find(".net.0.");
@@ -156,24 +192,59 @@ const std::vector<float> *param(se_engine *e, const std::string &key, size_t exp
 // taps: list of (kf, kt) with their patch offsets; wsel(ci, co, kf, kt) fetches the reference weight.
 template <class WSel>
 int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy, int s, int os, int oo, int colpad,
-              int tlo_off, int rows_extra, int St, const std::vector<std::array<int, 4>> &taps /*kf,kt,rowoff,coloff*/,
+              int tlo_off, int ngroup, int dil, int St, const std::vector<std::array<int, 4>> &taps /*kf,kt,rowgrp,coloff*/,
               WSel wsel, const std::vector<float> &bias, int relu_lo, int relu_hi) {
     pl.active = FP > 0;
     if (!pl.active) return 0;
     const int T = e->T;
+    const int ntap = (int)taps.size();
+    const int P = T * FP, tiles = (P + 31) / 32;
+    if (Co <= 4) {  // vector-ALU variant: one thread per position, weights [tap][ci][4]
+        const int tpw = 8, n_wg = (tiles + tpw - 1) / tpw;
+        int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
+        if (rows_pos > T) rows_pos = T;
+        const int grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+        const int Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
+        auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * 4 + (size_t)cc * Rmax * St); };
+        int CC = Ci;
+        while (CC > 1 && bytes(CC) > e->conv_lds_budget) CC--;
+        int nchunk = (Ci + CC - 1) / CC;
+        CC = (Ci + nchunk - 1) / nchunk;
+        nchunk = (Ci + CC - 1) / CC;
+        if ((ntap * CC) % 1) return fail(e, SE_ERR_ARG, "internal");
+        ConvArgs &a = pl.a;
+        a.Ci = Ci; a.Co = Co; a.CoPad = 4; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
+        a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
+        a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+        a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+        for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
+        pl.NT = 0;  // marks the small kernel
+        pl.grid_x = n_wg;
+        pl.lds = bytes(CC);
+        std::vector<float> w((size_t)nchunk * ntap * CC * 4, 0.0f);
+        for (int ch = 0; ch < nchunk; ch++)
+            for (int t = 0; t < ntap; t++)
+                for (int c = 0; c < CC; c++) {
+                    const int ci = ch * CC + c;
+                    if (ci >= Ci) continue;
+                    for (int co = 0; co < Co; co++) w[(((size_t)ch * ntap + t) * CC + c) * 4 + co] = wsel(ci, co, taps[t][0], taps[t][1]);
+                }
+        int rc = dev_upload(e, pl.w, w);
+        if (rc) return rc;
+        return dev_upload(e, pl.bias, bias);
+    }
     const int CoPad = (Co + 31) / 32 * 32;
     if (CoPad > 128) return fail(e, SE_ERR_ARG, "conv with %d output channels is not supported (max 128 per GEMM)", Co);
     const int MT = CoPad / 32;
     if (MT == 3) return fail(e, SE_ERR_ARG, "conv output channels %d need 3 row tiles (unsupported)", Co);
     const int NCG = 4 / MT, NTmax = 4;
-    const int P = T * FP, tiles = (P + 31) / 32;
     const int n_wg = (tiles + NCG * NTmax - 1) / (NCG * NTmax);
     const int tpw = (tiles + n_wg - 1) / n_wg;
     const int NT = (tpw + NCG - 1) / NCG;
-    const int ntap = (int)taps.size();
     int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
     if (rows_pos > T) rows_pos = T;
-    const int Rmax = rows_pos + rows_extra;
+    const int grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+    const int Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
     const int CiPad = (Ci + 1) / 2 * 2;
     auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * CoPad + (size_t)cc * Rmax * St); };
     int CC = CiPad;
@@ -184,10 +255,10 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     if (bytes(CC) > 150 * 1024) return fail(e, SE_ERR_ARG, "conv tile does not fit LDS (%zu bytes)", bytes(CC));
     ConvArgs &a = pl.a;
     a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
-    a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.rows_extra = rows_extra;
+    a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
     a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
     a.relu_lo = relu_lo; a.relu_hi = relu_hi;
-    for (int t = 0; t < ntap; t++) { a.rowoff[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
+    for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
     pl.NT = NT;
     pl.grid_x = n_wg;
     pl.lds = bytes(CC);
@@ -218,12 +289,13 @@ int prepare_weights(se_engine *e) {
         if (!w || !b || !nw || !nb) return SE_ERR_PARAM_MISSING;
         std::vector<std::array<int, 4>> taps;
         for (int kf = 0; kf < 5; kf++)
-            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, kt * d, kf});
+            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, kt, kf});
         const float *wp = w->data();
-        int rc = plan_conv(e, e->lv[i].enc, Ci, Co, Fo, Fi, Fo, 2, 1, 0, 2, -2 * d, 2 * d, Fi + 4, taps,
+        int rc = plan_conv(e, e->lv[i].enc, Ci, Co, Fo, Fi, Fo, 2, 1, 0, 2, -2 * d, 3, d, Fi + 4, taps,
                            [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; },
                            *b, 0, Co);
         if (rc) return rc;
+        e->lv[i].enc.flops = 2.0 * Co * Ci * 15 * Fo * e->T;
         if ((rc = dev_upload(e, e->lv[i].enc_nw, *nw))) return rc;
         if ((rc = dev_upload(e, e->lv[i].enc_nb, *nb))) return rc;
     }
@@ -240,13 +312,16 @@ int prepare_weights(se_engine *e) {
         auto wsel = [=](int ci, int co, int kf, int kt) { return wp[(((size_t)ci * Co + co) * 5 + kf) * 3 + kt]; };
         std::vector<std::array<int, 4>> te, to;
         for (int kf = 0; kf < 5; kf += 2)
-            for (int kt = 0; kt < 3; kt++) te.push_back({kf, kt, (2 - kt) * d, 2 - kf / 2});
+            for (int kt = 0; kt < 3; kt++) te.push_back({kf, kt, 2 - kt, 2 - kf / 2});
         for (int kf = 1; kf < 5; kf += 2)
-            for (int kt = 0; kt < 3; kt++) to.push_back({kf, kt, (2 - kt) * d, 1 + (3 - kf) / 2});
-        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 2 * d, Fi + 2, te, wsel, *b, 0, Co);
+            for (int kt = 0; kt < 3; kt++) to.push_back({kf, kt, 2 - kt, 1 + (3 - kf) / 2});
+        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, te, wsel, *b, 0, Co);
         if (rc) return rc;
-        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 2 * d, Fi + 2, to, wsel, *b, 0, Co);
+        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 3, d, Fi + 2, to, wsel, *b, 0, Co);
         if (rc) return rc;
+        // SURVEY 8d counts a transposed conv as Cin*Cout*15*Fi*T MACs; split 9:6 over the two parity launches
+        e->lv[j].dec_even.flops = 2.0 * Ci * Co * 9 * Fi * e->T;
+        e->lv[j].dec_odd.flops = 2.0 * Ci * Co * 6 * Fi * e->T;
         if ((rc = dev_upload(e, e->lv[j].dec_nw, *nw))) return rc;
         if ((rc = dev_upload(e, e->lv[j].dec_nb, *nb))) return rc;
         if (lvl > 0) {  // skip path exists (CRN.py:485-487)
@@ -262,10 +337,11 @@ int prepare_weights(se_engine *e) {
             for (int c = 0; c < Co; c++) { bias2[c] = (*mb)[c]; bias2[Co + c] = (*rb)[c]; }
             std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
             const int Fr = e->F[lvl];
-            rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 0, Fr, t1,
+            rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
                            [=](int ci, int co, int, int) { return co < Co ? mwp[(size_t)co * Co + ci] : rwp[(size_t)(co - Co) * Co + ci]; },
                            bias2, Co, 2 * Co);
             if (rc) return rc;
+            e->lv[j].skip.flops = 2.0 * 2 * Co * Co * Fr * e->T;
             if ((rc = dev_upload(e, e->lv[j].dec_mnw, *mnw))) return rc;
             if ((rc = dev_upload(e, e->lv[j].dec_mnb, *mnb))) return rc;
         }
@@ -298,23 +374,31 @@ int prepare_weights(se_engine *e) {
     return 0;
 }
 
-int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st) {
+int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st, const char *label) {
     if (!pl.active) return 0;
+    // algorithmic MACs of this launch as SURVEY.md 8d counts them are attributed by the caller via pl.flops
+    ProfScope ps(e, "k_conv_igemm", label, pl.flops * e->B, st);
     ConvArgs a = pl.a;
     a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p;
     dim3 grid(pl.grid_x, e->B);
-    switch (pl.NT) {
-        case 1: hipLaunchKernelGGL(k_conv_igemm<1>, grid, dim3(256), pl.lds, st, a); break;
-        case 2: hipLaunchKernelGGL(k_conv_igemm<2>, grid, dim3(256), pl.lds, st, a); break;
-        case 3: hipLaunchKernelGGL(k_conv_igemm<3>, grid, dim3(256), pl.lds, st, a); break;
-        default: hipLaunchKernelGGL(k_conv_igemm<4>, grid, dim3(256), pl.lds, st, a); break;
+#define SE_CONV_CASE(NTAP_, NT_) \
+    case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
+#define SE_CONV_TAPS(NTAP_) SE_CONV_CASE(NTAP_, 1) SE_CONV_CASE(NTAP_, 2) SE_CONV_CASE(NTAP_, 3) SE_CONV_CASE(NTAP_, 4) \
+    case NTAP_ * 8: hipLaunchKernelGGL((k_conv_small<NTAP_>), grid, dim3(256), pl.lds, st, a); break;
+    switch (a.ntap * 8 + pl.NT) {
+        SE_CONV_TAPS(15) SE_CONV_TAPS(9) SE_CONV_TAPS(6) SE_CONV_TAPS(1)
+        default: return fail(e, SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
     }
+#undef SE_CONV_TAPS
+#undef SE_CONV_CASE
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
 
 int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw, const float *bias, float *C, long ldc,
-                int Mr, int Nc, int Kd, int relu, hipStream_t st) {
+                int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label) {
+    ProfScope ps(e, "k_gemm_tn", label, 2.0 * Mr * Nc * Kd, st);
+    if (Kd % 4 || Kd < 4 || lda % 4 || ldw % 4) return fail(e, SE_ERR_ARG, "GEMM inner dimension %d must be a multiple of 4", Kd);
     GemmArgs g{A, W, bias, C, Mr, Nc, Kd, lda, ldw, ldc, relu};
     dim3 grid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, g);
@@ -324,6 +408,7 @@ int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw
 
 int launch_gln(se_engine *e, const float *x, float *y, const float *w, const float *b, long n, int mode, int C, int T,
                int F, hipStream_t st) {
+    ProfScope ps(e, "k_gln", "gln", 0, st);
     GlnArgs g{x, y, w, b, n, mode, C, T, F};
     hipLaunchKernelGGL(k_gln, dim3(e->B), dim3(1024), 0, st, g);
     HIPCHECK(e, hipGetLastError());
@@ -338,6 +423,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     e->parity ^= 1;
     const int cur = e->parity, prev = cur ^ 1;
     {  // features (CRN.py:463-467)
+        ProfScope ps(e, "k_featurize", "featurize", 0, st);
         FeatArgs f{spec, sB, sM, sT, sF, e->xin[0][cur].p, e->M, T, e->F[0]};
         const int TF = T * e->F[0];
         hipLaunchKernelGGL(k_featurize, dim3((TF + 255) / 256, B), dim3(256), 0, st, f);
@@ -345,7 +431,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     }
     for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474)
         const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
-        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st))) return rc;
+        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str()))) return rc;
         const long n = (long)Co * T * Fo;
         if (i + 1 < L) rc = launch_gln(e, e->enc_raw[i].p, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 0, Co, T, Fo, st);
         else rc = launch_gln(e, e->enc_raw[i].p, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 1, Co, T, Fo, st);
@@ -355,12 +441,13 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     const float *layer_in = e->gru_in.p;
     long in_dim = D;
     for (int l = 0; l < e->NL; l++) {
-        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st))) return rc;
+        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc;
         float *seq = e->seq[l & 1].p;
         for (int t = 0; t < T; t++) {
             const int hc = e->hcur[l];
             GruStepArgs g{e->gi.p + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
                           e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
+            ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
             hipLaunchKernelGGL(k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
             e->hcur[l] = hc ^ 1;
         }
@@ -368,26 +455,28 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
         layer_in = seq;
         in_dim = H;
     }
-    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st))) return rc;
+    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st, "gru_fc"))) return rc;
     if ((rc = launch_gln(e, e->fc_out.p, e->dec_in.p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st))) return rc;
     // decoder (CRN.py:483-489)
     const float *x = e->dec_in.p;
     for (int j = 0; j < L; j++) {
         const int lvl = L - 1 - j;
         const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1], Fo = 2 * Fi - 1;
-        if ((rc = launch_conv(e, e->lv[j].dec_even, x, nullptr, e->dec_raw[j].p, st))) return rc;
-        if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st))) return rc;
+        if ((rc = launch_conv(e, e->lv[j].dec_even, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_even").c_str()))) return rc;
+        if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_odd").c_str()))) return rc;
         if (lvl > 0) {
             const int Fr = e->F[lvl];
-            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st))) return rc;
+            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str()))) return rc;
             BlendArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
                          e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, Co, T, Fo, Fr};
+            ProfScope ps(e, "k_dec_blend", "dec_blend", 0, st);
             hipLaunchKernelGGL(k_dec_blend, dim3(B), dim3(1024), 0, st, bl);
             HIPCHECK(e, hipGetLastError());
             x = e->dec_out[j].p;
         } else {
             if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
             MaskArgs m{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
+            ProfScope ps(e, "k_final_mask", "final_mask", 0, st);
             hipLaunchKernelGGL(k_final_mask, dim3(B), dim3(1024), 0, st, m);
             HIPCHECK(e, hipGetLastError());
         }
@@ -402,6 +491,7 @@ int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int 
     a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF;
     a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+    ProfScope ps(e, "k_stft", "stft", 0, st);
     hipLaunchKernelGGL(k_stft, dim3(rows), dim3(256), stft_lds_bytes(e->K, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
@@ -411,6 +501,7 @@ int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int r
     IstftArgs a{};
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF; a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.wav = wav; a.wav_ld = wav_ld; a.window = e->window.p; a.env = e->env.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+    ProfScope ps(e, "k_istft", "istft", 0, st);
     hipLaunchKernelGGL(k_istft, dim3(rows), dim3(256), istft_lds_bytes(e->T, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
@@ -437,7 +528,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (L < 1 || L > SE_MAX_LEVELS) return fail(nullptr, SE_ERR_ARG, "num_levels %d out of range", L);
     if (cfg->kernel_size != 3) return fail(nullptr, SE_ERR_ARG, "kernel_size %d unsupported (reference config uses 3)", cfg->kernel_size);
     if (cfg->num_layers < 1 || cfg->num_layers > 4) return fail(nullptr, SE_ERR_ARG, "num_layers %d out of range", cfg->num_layers);
-    if (cfg->hidden <= 0 || cfg->hidden % 4) return fail(nullptr, SE_ERR_ARG, "hidden must be a positive multiple of 4 (16-byte operand loads)");
+    if (cfg->hidden <= 0 || cfg->hidden % 16) return fail(nullptr, SE_ERR_ARG, "hidden must be a positive multiple of 16 (k_gru_step walks 16-deep k blocks)");
     if (cfg->n_fft % 2 || cfg->num_freqs != cfg->n_fft / 2 + 1) return fail(nullptr, SE_ERR_ARG, "num_freqs must be n_fft/2+1 (CRN.py:511)");
     if (cfg->win > cfg->n_fft || cfg->hop <= 0 || cfg->segment_length % cfg->hop) return fail(nullptr, SE_ERR_ARG, "bad STFT geometry");
     int ndev = 0;
@@ -480,10 +571,14 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     // opt in to large dynamic LDS for the FFT kernels
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes(K, N));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)istft_lds_bytes(T, N));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SE_CONV_ATTR(NTAP_)                                                                                                        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
+#undef SE_CONV_ATTR
     *out = e;
     return SE_OK;
 }
@@ -763,5 +858,37 @@ double se_flops_per_frame(const se_engine *e) {
 }
 
 int se_frames_per_segment(const se_engine *e) { return e ? e->T : 0; }
+
+int se_profile(se_engine *e, int enable) {
+    if (!e) return SE_ERR_ARG;
+    HIPCHECK(e, hipSetDevice(e->device));
+    HIPCHECK(e, hipDeviceSynchronize());
+    for (auto &r : e->prof_recs) { e->prof_pool.push_back(r.a); e->prof_pool.push_back(r.b); }
+    e->prof_recs.clear();
+    for (auto &l : e->prof_labels) { l.ms = 0; l.launches = 0; }
+    e->prof_on = enable != 0;
+    return SE_OK;
+}
+
+int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap, double *ms_total, int64_t *launches, double *flops_per_launch) {
+    if (!e) return SE_ERR_ARG;
+    if (!e->prof_recs.empty()) {  // fold pending records
+        HIPCHECK(e, hipDeviceSynchronize());
+        for (auto &r : e->prof_recs) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { e->prof_labels[r.label].ms += ms; e->prof_labels[r.label].launches++; }
+            e->prof_pool.push_back(r.a); e->prof_pool.push_back(r.b);
+        }
+        e->prof_recs.clear();
+    }
+    if (index < 0 || index >= (int)e->prof_labels.size()) return 1;  // end of list
+    const auto &l = e->prof_labels[index];
+    if (kernel) snprintf(kernel, cap, "%s", l.kernel.c_str());
+    if (label) snprintf(label, cap, "%s", l.label.c_str());
+    if (ms_total) *ms_total = l.ms;
+    if (launches) *launches = l.launches;
+    if (flops_per_launch) *flops_per_launch = l.flops;
+    return SE_OK;
+}
 
 }  // extern "C"

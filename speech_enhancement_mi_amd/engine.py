@@ -19,7 +19,7 @@ SE_MAX_LEVELS = 8
 EXPORTS = [
     "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_step",
     "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
-    "se_import_state", "se_flops_per_frame", "se_frames_per_segment",
+    "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
 ]
 
 
@@ -63,6 +63,8 @@ def load_library():
     L.se_flops_per_frame.argtypes = [vp]
     L.se_flops_per_frame.restype = C.c_double
     L.se_frames_per_segment.argtypes = [vp]
+    L.se_profile.argtypes = [vp, C.c_int]
+    L.se_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -197,6 +199,24 @@ class Engine:
     def import_state(self, name: str, arr: np.ndarray):
         a = np.ascontiguousarray(arr, dtype=np.float32)
         self._check(self.lib.se_import_state(self._h, name.encode(), C.c_void_p(a.ctypes.data), a.size, self._stream()))
+
+    def profile(self, enable: bool):
+        self._check(self.lib.se_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """[{kernel, label, ms, launches, flops_per_launch}] accumulated since profile(True)."""
+        out = []
+        i = 0
+        while True:
+            k, l = C.create_string_buffer(64), C.create_string_buffer(64)
+            ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+            rc = self.lib.se_profile_read(self._h, i, k, l, 64, C.byref(ms), C.byref(n), C.byref(fl))
+            if rc == 1:
+                break
+            self._check(rc)
+            out.append(dict(kernel=k.value.decode(), label=l.value.decode(), ms=ms.value, launches=n.value, flops_per_launch=fl.value))
+            i += 1
+        return out
 
     @property
     def flops_per_frame(self) -> float:

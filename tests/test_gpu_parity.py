@@ -36,7 +36,7 @@ def _cuda(a):
 
 @pytest.mark.parametrize("name,cfg", [("400", FULL400), ("512", FULL512)])
 def test_stft_istft(golden, name, cfg):
-    e = _engine(dict(cfg, num_channels=[2, 2, 2, 2], hidden=4))
+    e = _engine(dict(cfg, num_channels=[2, 2, 2, 2], hidden=16))
     wav = golden["g2_wave"].reshape(-1, 3200)
     sp = e.stft(_cuda(wav)).cpu().numpy().reshape(2, 3, cfg["num_freqs"], 21, 2)
     assert np.abs(sp - golden[f"stft{name}_out"]).max() < 3e-5
@@ -46,11 +46,11 @@ def test_stft_istft(golden, name, cfg):
 
 
 def test_stft_zero_and_edges():
-    e = _engine(dict(FULL400, num_channels=[2, 2, 2, 2], hidden=4))
+    e = _engine(dict(FULL400, num_channels=[2, 2, 2, 2], hidden=16))
     z = e.stft(torch.zeros(3, 3200, device="cuda")).cpu().numpy()
     assert np.all(z == 0)
     from oracle import crn_oracle as orc
-    o = orc.CrnOracle(**dict(FULL400, num_channels=[2, 2, 2, 2], hidden=4))
+    o = orc.CrnOracle(**dict(FULL400, num_channels=[2, 2, 2, 2], hidden=16))
     x = np.zeros((2, 3200), np.float32)
     x[0, 0] = 1.0
     x[1, -1] = -1.0
