@@ -45,7 +45,27 @@ struct ConvArgs {
     int coloff[kMaxTaps];
     int CC, nchunk, tiles_per_wg, St;
     int relu_lo, relu_hi;  // output channels in [relu_lo, relu_hi) get ReLU
+    // per-workgroup partial (sum, sum of squares) of the stored activations of channels [stats_lo, stats_hi),
+    // written to stats[(b*stats_nslot + stats_slot0 + blockIdx.x)*2 + {0,1}] for the global layer norm that
+    // follows every block (CRN.py:135-149); nullptr = off.  One slot per workgroup -> deterministic.
+    float *stats;
+    int stats_nslot, stats_slot0, stats_lo, stats_hi;
 };
+
+// block-wide sum of (s, q) over 256 threads -> one slab slot
+__device__ __forceinline__ void conv_stats_store(const ConvArgs &a, float s, float q, float *red /*[8]*/, int b) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *o = a.stats + ((long)b * a.stats_nslot + a.stats_slot0 + blockIdx.x) * 2;
+        o[0] = (red[0] + red[2]) + (red[4] + red[6]);
+        o[1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
 
 // Stages one Cin-chunk of the input patch (zero halo, causal history from xprev) and of the weights.
 // Row bookkeeping (channel, time-tap group, row -> source pointer, LDS row, validity) is wave-uniform and kept
@@ -199,9 +219,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
             }
         }
     }
-    // ---- epilogue: bias, ReLU, store [B][Co][T][Fy] ----
+    // ---- epilogue: bias, ReLU, store [B][Co][T][Fy], partial norm statistics ----
     const long ys_c = (long)a.T * a.Fy;
     float *yb = a.y + (long)b * a.Co * ys_c;
+    float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         if (!lane_ok[i]) continue;
@@ -213,67 +234,71 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
                 float v = acc[i][r] + a.bias[co];
                 if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
                 yp[co * ys_c] = v;
+                if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
             }
         }
     }
+    if (a.stats) conv_stats_store(a, ssum, ssq, lds, b);  // lds is free again: all waves are past the MFMA loop
 }
 
-// Same tiling on the vector ALU for convolutions with <= 4 output channels (the last decoder block,
-// 16 -> 2 channels: a 32-row MFMA tile would be 94 % padding).  One thread per output position,
-// weights broadcast from LDS as float4 ([tap][ci][4]).
+// Convolutions with <= 4 output channels (the last decoder block, 16 -> 2 channels: a 32-row MFMA tile would be
+// 94 % padding) run on the vector ALU, one thread per output position, reading the input straight from
+// L2/HBM: consecutive lanes read consecutive frequencies (coalesced) and all NTAP x Cin loads of a thread are
+// independent, so the memory system stays full; an LDS patch (as in k_conv_igemm) would re-stage a 3-time-tap
+// halo that is 8x larger than the two output rows a workgroup produces.  Weights [tap][ci][4] sit in LDS and
+// are read as broadcast float4.
 template <int NTAP>
 __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int P = a.T * a.FP;
-    const int p0 = blockIdx.x * a.tiles_per_wg * 32;
-    if (p0 >= P) return;
-    const int p1 = min(P, p0 + a.tiles_per_wg * 32);
-    const int ta = p0 / a.FP, tb = (p1 - 1) / a.FP;
-    const int RT = tb - ta + 1;
-    const int R = a.grouped ? a.ngroup * RT : RT + (a.ngroup - 1) * a.dil;
-    const int St = a.St, Sc = R * St, CC = a.CC;
-    float *wl = lds;                      // [NTAP][CC][4]
-    float *patch = lds + NTAP * CC * 4;   // [CC][R][St]
-    const int p = p0 + tid;
-    const bool ok = p < p1;
-    const int pc = ok ? p : (p1 - 1);
+    const int nw = NTAP * a.Ci * 4;  // host lays the weights out as ONE chunk: [NTAP][Ci][4]
+    for (int i = tid; i < nw; i += 256) lds[i] = a.w[i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + tid;
+    const bool live = p < P;
+    const int pc = live ? p : P - 1;
     const int t = pc / a.FP, m = pc - t * a.FP;
-    const int base = (t - ta) * St + a.s * m;
-    int toff[NTAP];
-#pragma unroll
-    for (int k = 0; k < NTAP; k++) toff[k] = a.rowgrp[k] * (a.grouped ? RT : a.dil) * St + a.coloff[k];
-    float4 acc = make_float4(0, 0, 0, 0);
     const long xs_c = (long)a.T * a.Fi;
     const float *xb = a.x + (long)b * a.Ci * xs_c;
-    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : nullptr;
-    const int wslab = NTAP * CC * 4;
-    for (int ch = 0; ch < a.nchunk; ch++) {
-        __syncthreads();
-        conv_stage(a, wl, patch, xb, xpb, xs_c, ch, RT, R, Sc, ta, wslab, tid);
-        __syncthreads();
-        for (int c = 0; c < CC; c++) {
-            const float *pc_ = patch + c * Sc + base;
+    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : xb;
+    const float *src[NTAP];
+    bool ok[NTAP];
 #pragma unroll
-            for (int tap = 0; tap < NTAP; tap++) {
-                const float v = pc_[toff[tap]];
-                const float4 w = *reinterpret_cast<const float4 *>(wl + (tap * CC + c) * 4);
-                acc.x += w.x * v; acc.y += w.y * v; acc.z += w.z * v; acc.w += w.w * v;
-            }
+    for (int k = 0; k < NTAP; k++) {
+        const int ts = t + a.tlo_off + a.rowgrp[k] * a.dil;
+        const int fi = a.s * m + a.coloff[k] - a.colpad;
+        const bool hist = ts < 0;
+        ok[k] = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
+        const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1), fic = min(max(fi, 0), a.Fi - 1);
+        src[k] = (hist ? xpb : xb) + (long)tsc * a.Fi + fic;
+    }
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int c = 0; c < a.Ci; c++) {
+        float v[NTAP];
+#pragma unroll
+        for (int k = 0; k < NTAP; k++) v[k] = src[k][c * xs_c];
+#pragma unroll
+        for (int k = 0; k < NTAP; k++) {
+            const float x = ok[k] ? v[k] : 0.0f;
+            const float4 w = *reinterpret_cast<const float4 *>(lds + (k * a.Ci + c) * 4);
+            acc.x += w.x * x; acc.y += w.y * x; acc.z += w.z * x; acc.w += w.w * x;
         }
     }
-    if (!ok) return;
     const long ys_c = (long)a.T * a.Fy;
     float *yp = a.y + (long)b * a.Co * ys_c + (long)t * a.Fy + a.os * m + a.oo;
     const float r4[4] = {acc.x, acc.y, acc.z, acc.w};
+    float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
     for (int co = 0; co < 4; co++)
-        if (co < a.Co) {
+        if (co < a.Co && live) {
             float v = r4[co] + a.bias[co];
             if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
             yp[co * ys_c] = v;
+            if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
         }
+    if (a.stats) conv_stats_store(a, ssum, ssq, lds, b);
 }
 
 }  // namespace se

@@ -174,6 +174,141 @@ __global__ __launch_bounds__(1024) void k_final_mask(MaskArgs a) {
     }
 }
 
+// ---- elementwise variants: statistics come from the producing convolution's per-workgroup partials ----------
+// (one pass over the tensor instead of three, full-chip grid instead of one workgroup per stream)
+struct SlabStats { const float *slab; int nslot; long n; };  // slab [B][nslot][2] = (sum, sum of squares)
+
+__device__ __forceinline__ void slab_mean_inv(const SlabStats &st, int b, float *sm /*[2] shared*/, float &mean, float &inv) {
+    if (threadIdx.x < 64) {
+        double s = 0, q = 0;
+        const float *p = st.slab + (long)b * st.nslot * 2;
+        for (int i = threadIdx.x; i < st.nslot; i += 64) { s += (double)p[2 * i]; q += (double)p[2 * i + 1]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+        if (threadIdx.x == 0) {
+            const double m = s / (double)st.n;
+            double var = q / (double)st.n - m * m;
+            if (var < 0) var = 0;
+            sm[0] = (float)m;
+            sm[1] = 1.0f / (sqrtf((float)var + kEps) + kEps);
+        }
+    }
+    __syncthreads();
+    mean = sm[0];
+    inv = sm[1];
+}
+
+struct GlnEwArgs {
+    const float *x;
+    float *y;
+    const float *w, *b;
+    SlabStats st;
+    int mode;  // 0: [C][T][F] -> same | 1: [C][T][F] -> [T][C*F]
+    int C, T, F;
+};
+
+__global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
+    __shared__ float sm[2];
+    const int b = blockIdx.y;
+    float mean, inv;
+    slab_mean_inv(a.st, b, sm, mean, inv);
+    const long n = a.st.n;
+    const float *x = a.x + (long)b * n;
+    float *y = a.y + (long)b * n;
+    const int TF = a.T * a.F, F = a.F, C = a.C;
+    const float invTF = 1.0f / (float)TF;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + i);  // n % 4 == 0 (host-checked)
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        int cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int c = (int)(((float)(i + k) + 0.5f) * invTF);  // (i+k) / TF, exact for n < 2^22
+            c = min(c, C - 1);
+            cc[k] = c;
+            o[k] = (vv[k] - mean) * inv * a.w[c] + a.b[c];
+        }
+        if (a.mode == 0) {
+            *reinterpret_cast<float4 *>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = (int)(i + k) - cc[k] * TF, t = r / F, f = r - t * F;
+                y[((long)t * C + cc[k]) * F + f] = o[k];
+            }
+        }
+    }
+}
+
+struct BlendEwArgs {
+    const float *y, *uv;
+    float *out;
+    const float *nw, *nb, *mnw, *mnb;
+    SlabStats sy, su;
+    int Co, T, Fo, Fr;
+};
+
+__global__ __launch_bounds__(256) void k_dec_blend_ew(BlendEwArgs a) {
+    __shared__ float sm[4];
+    const int b = blockIdx.y;
+    float my, iy, mu, iu;
+    slab_mean_inv(a.sy, b, sm, my, iy);
+    slab_mean_inv(a.su, b, sm + 2, mu, iu);
+    const long ny = (long)a.Co * a.T * a.Fo, nu = (long)a.Co * a.T * a.Fr;
+    const float *y = a.y + b * ny;
+    const float *u = a.uv + (long)b * 2 * nu;
+    const float *v = u + nu;
+    float *o = a.out + b * nu;
+    const int TFr = a.T * a.Fr;
+    const float invTFr = 1.0f / (float)TFr, invFr = 1.0f / (float)a.Fr;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nu; i += (long)gridDim.x * blockDim.x * 4) {
+        const float4 u4 = *reinterpret_cast<const float4 *>(u + i);
+        const float4 v4 = *reinterpret_cast<const float4 *>(v + i);
+        const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float r4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int c = min((int)(((float)(i + k) + 0.5f) * invTFr), a.Co - 1);
+            const int r = (int)(i + k) - c * TFr;
+            int t = min((int)(((float)r + 0.5f) * invFr), a.T - 1);
+            const int f = r - t * a.Fr;
+            const float yv = f < a.Fo ? (y[((long)c * a.T + t) * a.Fo + f] - my) * iy * a.nw[c] + a.nb[c] : 0.0f;
+            const float un = (uu[k] - mu) * iu * a.mnw[c] + a.mnb[c];
+            const float m = 1.0f / (1.0f + expf(-un));
+            r4[k] = m * vv[k] + (1.0f - m) * yv;
+        }
+        *reinterpret_cast<float4 *>(o + i) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    }
+}
+
+struct MaskEwArgs {
+    const float *y;
+    const float *nw, *nb;
+    SlabStats st;
+    const cf2 *spec;
+    long sB, sT, sF;
+    cf2 *out;
+    long oB, oT, oF;
+    int T, F;
+};
+
+__global__ __launch_bounds__(256) void k_final_mask_ew(MaskEwArgs a) {
+    __shared__ float sm[2];
+    const int b = blockIdx.y;
+    float mean, inv;
+    slab_mean_inv(a.st, b, sm, mean, inv);
+    const int TF = a.T * a.F;
+    const float *y = a.y + (long)b * 2 * TF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TF; i += gridDim.x * blockDim.x) {
+        const int t = i / a.F, f = i - t * a.F;
+        const float mr = decompress_cirm((y[i] - mean) * inv * a.nw[0] + a.nb[0]);
+        const float mi = decompress_cirm((y[TF + i] - mean) * inv * a.nw[1] + a.nb[1]);
+        const cf2 n = a.spec[(long)b * a.sB + (long)t * a.sT + (long)f * a.sF];
+        a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * n.x - mi * n.y, mi * n.x + mr * n.y};
+    }
+}
+
 // ---- layout converters for the debug taps / state hand-over ([B][C][T][F] <-> reference [B][C][F][T]) ----
 __global__ void k_ctf_to_cft(const float *src, float *dst, long BC, int T, int F) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

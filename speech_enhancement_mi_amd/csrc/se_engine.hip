@@ -86,6 +86,7 @@ struct se_engine {
     DevBuf gru_in, gi, seq[2], hbuf[4][2], fc_out, dec_in;
     int hcur[4]{};
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
+    DevBuf enc_stats[SE_MAX_LEVELS], dec_stats[SE_MAX_LEVELS], skip_stats[SE_MAX_LEVELS];  // [B][slots][2] norm partials
     DevBuf yseg, scratch;
 
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -199,36 +200,21 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int T = e->T;
     const int ntap = (int)taps.size();
     const int P = T * FP, tiles = (P + 31) / 32;
-    if (Co <= 4) {  // vector-ALU variant: one thread per position, weights [tap][ci][4]
-        const int tpw = 8, n_wg = (tiles + tpw - 1) / tpw;
-        int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
-        if (rows_pos > T) rows_pos = T;
-        const int grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
-        const int Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
-        auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * 4 + (size_t)cc * Rmax * St); };
-        int CC = Ci;
-        while (CC > 1 && bytes(CC) > e->conv_lds_budget) CC--;
-        int nchunk = (Ci + CC - 1) / CC;
-        CC = (Ci + nchunk - 1) / nchunk;
-        nchunk = (Ci + CC - 1) / CC;
-        if ((ntap * CC) % 1) return fail(e, SE_ERR_ARG, "internal");
+    if (Co <= 4) {  // vector-ALU variant: one thread per position, direct global reads, weights [tap][ci][4] in LDS
         ConvArgs &a = pl.a;
         a.Ci = Ci; a.Co = Co; a.CoPad = 4; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
-        a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
-        a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+        a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = 0;
+        a.ntap = ntap; a.CC = Ci; a.nchunk = 1; a.tiles_per_wg = 8; a.St = St;
         a.relu_lo = relu_lo; a.relu_hi = relu_hi;
         for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
         pl.NT = 0;  // marks the small kernel
-        pl.grid_x = n_wg;
-        pl.lds = bytes(CC);
-        std::vector<float> w((size_t)nchunk * ntap * CC * 4, 0.0f);
-        for (int ch = 0; ch < nchunk; ch++)
-            for (int t = 0; t < ntap; t++)
-                for (int c = 0; c < CC; c++) {
-                    const int ci = ch * CC + c;
-                    if (ci >= Ci) continue;
-                    for (int co = 0; co < Co; co++) w[(((size_t)ch * ntap + t) * CC + c) * 4 + co] = wsel(ci, co, taps[t][0], taps[t][1]);
-                }
+        pl.grid_x = (P + 255) / 256;
+        pl.lds = sizeof(float) * (size_t)ntap * Ci * 4;
+        if (pl.lds > 64 * 1024) return fail(e, SE_ERR_ARG, "small-conv weights do not fit LDS");
+        std::vector<float> w((size_t)ntap * Ci * 4, 0.0f);
+        for (int t = 0; t < ntap; t++)
+            for (int ci = 0; ci < Ci; ci++)
+                for (int co = 0; co < Co; co++) w[((size_t)t * Ci + ci) * 4 + co] = wsel(ci, co, taps[t][0], taps[t][1]);
         int rc = dev_upload(e, pl.w, w);
         if (rc) return rc;
         return dev_upload(e, pl.bias, bias);
@@ -374,12 +360,14 @@ int prepare_weights(se_engine *e) {
     return 0;
 }
 
-int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st, const char *label) {
+int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st, const char *label,
+                float *stats = nullptr, int nslot = 0, int slot0 = 0, int stats_lo = 0, int stats_hi = 0) {
     if (!pl.active) return 0;
     // algorithmic MACs of this launch as SURVEY.md 8d counts them are attributed by the caller via pl.flops
     ProfScope ps(e, "k_conv_igemm", label, pl.flops * e->B, st);
     ConvArgs a = pl.a;
     a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p;
+    a.stats = stats; a.stats_nslot = nslot; a.stats_slot0 = slot0; a.stats_lo = stats_lo; a.stats_hi = stats_hi;
     dim3 grid(pl.grid_x, e->B);
 #define SE_CONV_CASE(NTAP_, NT_) \
     case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
@@ -415,6 +403,17 @@ int launch_gln(se_engine *e, const float *x, float *y, const float *w, const flo
     return 0;
 }
 
+int launch_gln_ew(se_engine *e, const float *x, float *y, const float *w, const float *b, const float *slab, int nslot, long n,
+                  int mode, int C, int T, int F, hipStream_t st) {
+    if (n % 4) return fail(e, SE_ERR_ARG, "tensor size %ld not a multiple of 4", n);
+    ProfScope ps(e, "k_gln_ew", "gln", 0, st);
+    GlnEwArgs g{x, y, w, b, SlabStats{slab, nslot, n}, mode, C, T, F};
+    const int gx = (int)((n / 4 + 256 * 4 - 1) / (256 * 4));
+    hipLaunchKernelGGL(k_gln_ew, dim3(gx, e->B), dim3(256), 0, st, g);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
 // TemporalCRN.forward on device.  spec: (b, m, t, f) strides; out: (b, t, f) strides (cf2 units).
 int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long sF, cf2 *out, long oB, long oT, long oF,
                 hipStream_t st) {
@@ -431,10 +430,12 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     }
     for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474)
         const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
-        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str()))) return rc;
+        const int ns = e->lv[i].enc.grid_x;
+        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str(),
+                              e->enc_stats[i].p, ns, 0, 0, Co))) return rc;
         const long n = (long)Co * T * Fo;
-        if (i + 1 < L) rc = launch_gln(e, e->enc_raw[i].p, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 0, Co, T, Fo, st);
-        else rc = launch_gln(e, e->enc_raw[i].p, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, n, 1, Co, T, Fo, st);
+        if (i + 1 < L) rc = launch_gln_ew(e, e->enc_raw[i].p, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 0, Co, T, Fo, st);
+        else rc = launch_gln_ew(e, e->enc_raw[i].p, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 1, Co, T, Fo, st);
         if (rc) return rc;
     }
     // bottleneck (CRN.py:476-481, 256-282)
@@ -462,22 +463,29 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     for (int j = 0; j < L; j++) {
         const int lvl = L - 1 - j;
         const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1], Fo = 2 * Fi - 1;
-        if ((rc = launch_conv(e, e->lv[j].dec_even, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_even").c_str()))) return rc;
-        if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_odd").c_str()))) return rc;
+        const int ne = e->lv[j].dec_even.active ? e->lv[j].dec_even.grid_x : 0, no = e->lv[j].dec_odd.active ? e->lv[j].dec_odd.grid_x : 0;
+        if ((rc = launch_conv(e, e->lv[j].dec_even, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_even").c_str(),
+                              e->dec_stats[j].p, ne + no, 0, 0, Co))) return rc;
+        if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_odd").c_str(),
+                              e->dec_stats[j].p, ne + no, ne, 0, Co))) return rc;
+        const SlabStats sy{e->dec_stats[j].p, ne + no, (long)Co * T * Fo};
         if (lvl > 0) {
-            const int Fr = e->F[lvl];
-            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str()))) return rc;
-            BlendArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
-                         e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, Co, T, Fo, Fr};
-            ProfScope ps(e, "k_dec_blend", "dec_blend", 0, st);
-            hipLaunchKernelGGL(k_dec_blend, dim3(B), dim3(1024), 0, st, bl);
+            const int Fr = e->F[lvl], nk = e->lv[j].skip.grid_x;
+            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str(),
+                                  e->skip_stats[j].p, nk, 0, 0, Co))) return rc;
+            const long nu = (long)Co * T * Fr;
+            if (nu % 4) return fail(e, SE_ERR_ARG, "decoder tensor size %ld not a multiple of 4", nu);
+            BlendEwArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
+                           e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy, SlabStats{e->skip_stats[j].p, nk, nu}, Co, T, Fo, Fr};
+            ProfScope ps(e, "k_dec_blend_ew", "dec_blend", 0, st);
+            hipLaunchKernelGGL(k_dec_blend_ew, dim3((unsigned)((nu / 4 + 1023) / 1024), B), dim3(256), 0, st, bl);
             HIPCHECK(e, hipGetLastError());
             x = e->dec_out[j].p;
         } else {
             if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
-            MaskArgs m{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
-            ProfScope ps(e, "k_final_mask", "final_mask", 0, st);
-            hipLaunchKernelGGL(k_final_mask, dim3(B), dim3(1024), 0, st, m);
+            MaskEwArgs m{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, sy, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
+            ProfScope ps(e, "k_final_mask_ew", "final_mask", 0, st);
+            hipLaunchKernelGGL(k_final_mask_ew, dim3((T * e->F[0] + 1023) / 1024, B), dim3(256), 0, st, m);
             HIPCHECK(e, hipGetLastError());
         }
     }
@@ -600,6 +608,7 @@ void se_destroy(se_engine *e) {
         for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
         dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
+        dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]);
     }
     delete e;
 }
@@ -648,6 +657,9 @@ int se_reset(se_engine *e, int batch) {
             HIPCHECK(e, hipMemset(e->xin[i][p].p, 0, nin * sizeof(float)));
         }
         if ((rc = dev_alloc(e, e->enc_raw[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
+        if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * e->lv[i].enc.grid_x))) return rc;
+        if ((rc = dev_alloc(e, e->dec_stats[i], (size_t)B * 2 * (e->lv[i].dec_even.grid_x + e->lv[i].dec_odd.grid_x + 1)))) return rc;
+        if ((rc = dev_alloc(e, e->skip_stats[i], (size_t)B * 2 * (e->lv[i].skip.grid_x + 1)))) return rc;
         const int lvl = L - 1 - i;  // decoder index i
         const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fo = 2 * e->F[lvl + 1] - 1, Fr = e->F[lvl];
         if ((rc = dev_alloc(e, e->dec_raw[i], (size_t)B * Co * T * Fo))) return rc;
