@@ -67,67 +67,44 @@ __device__ __forceinline__ void conv_stats_store(const ConvArgs &a, float s, flo
     }
 }
 
-// Stages one Cin-chunk of the input patch (zero halo, causal history from xprev) and of the weights.
-// Row bookkeeping (channel, time-tap group, row -> source pointer, LDS row, validity) is wave-uniform and kept
-// on the scalar unit (no per-element integer divisions); each lane only adds its column.  Loads are issued in
-// batches of 8 independent rows per wave before any LDS store, so ~8 global loads per lane are in flight.
-__device__ __forceinline__ void conv_stage(const ConvArgs &a, float *wl, float *patch, const float *xb, const float *xpb,
-                                           long xs_c, int ch, int RT, int R, int Sc, int ta, int wslab, int tid) {
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int CC = a.CC, St = a.St, ci0 = ch * CC;
-    const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
-    constexpr int U = 8;
-    for (int col0 = 0; col0 < St; col0 += 64) {
-        const int col = col0 + lane;
-        const int fi = col - a.colpad;
-        const bool col_ok = col < St;
-        const bool f_ok = col_ok && fi >= 0 && fi < a.Fi;
-        const int fic = min(max(fi, 0), a.Fi - 1);
-        int c = 0, g = 0, j = wave;  // this wave's row cursor (rows wave, wave+4, ... of the [CC][NGp][RTp] patch)
-        while (c < CC) {
-            float v[U];
-            int ldsrow[U];
+constexpr int kPatchPerThread = 16;   // patch elements staged per thread per chunk  (chunk patch <= 4096 floats)
+constexpr int kWeightPerThread = 8;   // float4 weight slots per thread per chunk      (chunk slab  <= 8192 floats)
+
+// Issues (does not wait for) the global loads of chunk `ch`: this thread's patch elements and weight slots.
+__device__ __forceinline__ void conv_issue_loads(const ConvArgs &a, int ch, int tid, int CC, int Sc, int npatch, long xs_c,
+                                                 const float *xb, const float *xpb, const int (&goff)[kPatchPerThread],
+                                                 unsigned okmask, unsigned histmask, int wslab, int n4,
+                                                 float (&pv)[kPatchPerThread], f32x4 (&wv)[kWeightPerThread]) {
+    const int cbase = ch * CC;
+    const int cmaxe = (a.Ci - cbase) * Sc;  // elements of channels >= Ci are zero
+    const long chan_off = (long)cbase * xs_c;
+    // the last chunk may be partial: clamp the base so every address stays inside x
+    const long safe_off = (long)min(cbase, max(a.Ci - CC, 0)) * xs_c;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                while (j >= RTp) { j -= RTp; if (++g == NGp) { g = 0; c++; } }
-                const bool row_in = c < CC;
-                const int cc_ = row_in ? c : CC - 1;
-                const int ts = ta + a.tlo_off + g * a.dil + j;
-                const bool hist = ts < 0;
-                const float *base = (hist && xpb) ? xpb : xb;
-                const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1);
-                const int ci = min(ci0 + cc_, a.Ci - 1);
-                const bool row_ok = row_in && (ci0 + cc_ < a.Ci) && (hist ? (xpb != nullptr && ts + a.T >= 0) : ts < a.T);
-                const float x = base[ci * xs_c + (long)tsc * a.Fi + fic];
-                v[u] = (row_ok && f_ok) ? x : 0.0f;
-                ldsrow[u] = row_in ? cc_ * Sc + (g * RTp + j) * St : -1;
-                j += 4;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (ldsrow[u] >= 0 && col_ok) patch[ldsrow[u] + col] = v[u];
-        }
+    for (int k = 0; k < kPatchPerThread; k++) {
+        const int e = tid + 256 * k;
+        const bool in = e < min(cmaxe, npatch);
+        const float *base = ((histmask >> k) & 1u) ? xpb : xb;
+        pv[k] = base[(in ? chan_off : safe_off) + goff[k]];  // raw: the zero mask is applied at the LDS write,
+                                                              // so no load is waited for here
     }
-    const float4 *wsrc = reinterpret_cast<const float4 *>(a.w + (long)ch * wslab);
-    float4 *wdst = reinterpret_cast<float4 *>(wl);
-    const int n4 = wslab >> 2;
-    for (int i0 = tid; i0 < n4; i0 += 256 * 4) {
-        float4 q[4];
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(a.w + (long)ch * wslab);
 #pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = wsrc[min(i0 + u * 256, n4 - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i0 + u * 256 < n4) wdst[i0 + u * 256] = q[u];
-    }
+    for (int k = 0; k < kWeightPerThread; k++) wv[k] = wsrc[min(tid + 256 * k, n4 - 1)];
 }
 
 // NTAP = number of taps of this tap set (15 encoder, 9 / 6 transposed even / odd, 1 for 1x1): a template
 // parameter so the tap loop unrolls and the per-tap LDS offsets live in SGPRs; NT = column tiles per wave.
-// The MFMA loop is branch-free: column tiles beyond the workgroup's range read a clamped address and
-// their accumulators are simply never stored.
+//
+// Staging is a register-prefetch pipeline: every thread owns up to 16 fixed patch elements and 8 float4 weight
+// slots of a chunk.  Their global offsets never change from chunk to chunk except for the channel base, so the
+// gather plan (offset, zero-halo / history flags) is computed once per workgroup; while the MFMAs of chunk k run
+// out of LDS, the loads of chunk k+1 are already in flight into registers and are written to LDS after the
+// barrier.  Global-memory latency is therefore hidden inside one workgroup instead of relying on neighbours.
+// The MFMA loop is branch-free: column tiles beyond the workgroup's range read a clamped address and their
+// accumulators are simply never stored.
 template <int NTAP, int NT>
-__global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
@@ -170,14 +147,52 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
 
     const long xs_c = (long)a.T * a.Fi;  // channel stride in x
     const float *xb = a.x + (long)b * a.Ci * xs_c;
-    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : nullptr;
-    const int wslab = NTAP * CC * CoPad;
+    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : xb;
+    const int wslab = NTAP * CC * CoPad, n4 = wslab >> 2;
+    const int npatch = CC * Sc;
     const int hk = CC >> 1;
+
+    // ---- gather plan: element e = tid + 256*k of the chunk patch [CC][R][St] ----
+    int goff[kPatchPerThread];
+    unsigned okmask = 0, histmask = 0;
+    {
+        const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
+#pragma unroll
+        for (int k = 0; k < kPatchPerThread; k++) {
+            const int e = min(tid + 256 * k, npatch - 1);
+            const int row = e / St, col = e - row * St;
+            const int c = row / R, r = row - c * R;
+            const int g = NGp > 1 ? r / RTp : 0, j = r - g * RTp;
+            const int ts = ta + a.tlo_off + g * a.dil + j;
+            const int fi = col - a.colpad;
+            const bool hist = ts < 0;
+            const bool ok = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
+            const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1), fic = min(max(fi, 0), a.Fi - 1);
+            goff[k] = c * (int)xs_c + tsc * a.Fi + fic;
+            okmask |= (ok ? 1u : 0u) << k;
+            histmask |= (hist ? 1u : 0u) << k;
+        }
+    }
+    float pv[kPatchPerThread];
+    f32x4 wv[kWeightPerThread];
+    conv_issue_loads(a, 0, tid, CC, Sc, npatch, xs_c, xb, xpb, goff, okmask, histmask, wslab, n4, pv, wv);
 
     for (int ch = 0; ch < a.nchunk; ch++) {
         __syncthreads();  // previous chunk fully consumed
-        conv_stage(a, wl, patch, xb, xpb, xs_c, ch, RT, R, Sc, ta, wslab, tid);
+        {
+            const int cmaxe = (a.Ci - ch * CC) * Sc;  // elements of channels >= Ci are zero
+#pragma unroll
+            for (int k = 0; k < kPatchPerThread; k++) {
+                const int e = tid + 256 * k;
+                if (e < npatch) patch[e] = (e < cmaxe && ((okmask >> k) & 1u)) ? pv[k] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWeightPerThread; k++)
+            if (tid + 256 * k < n4) reinterpret_cast<f32x4 *>(wl)[tid + 256 * k] = wv[k];
         __syncthreads();
+        if (ch + 1 < a.nchunk)  // in flight during the MFMAs below
+            conv_issue_loads(a, ch + 1, tid, CC, Sc, npatch, xs_c, xb, xpb, goff, okmask, histmask, wslab, n4, pv, wv);
         // software pipeline, one (tap, channel pair) step deep: the LDS reads of step s+1 are issued before
         // the NT MFMAs of step s (256 matrix-pipe cycles cover the ~100-cycle LDS latency).
         int wofs = mt * 32 + l31 + half * CoPad;  // A fragment offset inside wl (floats)
@@ -219,6 +234,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvArgs a) {
             }
         }
     }
+    __syncthreads();
     // ---- epilogue: bias, ReLU, store [B][Co][T][Fy], partial norm statistics ----
     const long ys_c = (long)a.T * a.Fy;
     float *yb = a.y + (long)b * a.Co * ys_c;

@@ -234,7 +234,12 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int CiPad = (Ci + 1) / 2 * 2;
     auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * CoPad + (size_t)cc * Rmax * St); };
     int CC = CiPad;
-    while (CC > 2 && bytes(CC) > e->conv_lds_budget) CC -= 2;
+    auto fits = [&](int cc) {
+        return bytes(cc) <= e->conv_lds_budget && (size_t)cc * Rmax * St <= 256 * kPatchPerThread &&
+               (size_t)ntap * cc * CoPad <= 256 * 4 * kWeightPerThread;
+    };
+    while (CC > 2 && !fits(CC)) CC -= 2;
+    if (!fits(CC)) return fail(e, SE_ERR_ARG, "conv chunk does not fit the staging registers (Rmax %d, St %d, taps %d, Cout %d)", Rmax, St, ntap, Co);
     int nchunk = (CiPad + CC - 1) / CC;
     CC = ((CiPad + nchunk - 1) / nchunk + 1) / 2 * 2;
     nchunk = (CiPad + CC - 1) / CC;
@@ -642,7 +647,8 @@ int se_load_param(se_engine *e, const char *key, const float *host_data, const i
     return SE_OK;
 }
 
-int se_reset(se_engine *e, int batch) {
+// (Re)allocates state for `batch` streams if needed and zeroes it asynchronously on `st`.
+static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     if (!e || batch <= 0) return fail(e, SE_ERR_ARG, "batch must be positive");
     int rc = ensure_ready(e);
     if (rc) return rc;
@@ -654,7 +660,7 @@ int se_reset(se_engine *e, int batch) {
         const size_t nin = (size_t)B * e->Ch[i] * T * e->F[i];
         for (int p = 0; p < 2; p++) {
             if ((rc = dev_alloc(e, e->xin[i][p], nin))) return rc;
-            HIPCHECK(e, hipMemset(e->xin[i][p].p, 0, nin * sizeof(float)));
+            HIPCHECK(e, hipMemsetAsync(e->xin[i][p].p, 0, nin * sizeof(float), st));
         }
         if ((rc = dev_alloc(e, e->enc_raw[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
         if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * e->lv[i].enc.grid_x))) return rc;
@@ -675,10 +681,16 @@ int se_reset(se_engine *e, int batch) {
     for (int l = 0; l < e->NL; l++)
         for (int p = 0; p < 2; p++) {
             if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
-            HIPCHECK(e, hipMemset(e->hbuf[l][p].p, 0, (size_t)B * H * sizeof(float)));
+            HIPCHECK(e, hipMemsetAsync(e->hbuf[l][p].p, 0, (size_t)B * H * sizeof(float), st));
         }
     for (int l = 0; l < 4; l++) e->hcur[l] = 0;
     e->parity = 0;
+    return SE_OK;
+}
+
+int se_reset(se_engine *e, int batch) {
+    int rc = reset_on_stream(e, batch, nullptr);
+    if (rc) return rc;
     HIPCHECK(e, hipDeviceSynchronize());
     return SE_OK;
 }
@@ -729,7 +741,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
     if (!e || !mixture || !out || batch <= 0 || length <= 0) return fail(e, SE_ERR_ARG, "bad argument");
     int rc;
     if (!flag) {
-        if ((rc = se_reset(e, batch))) return rc;  // CRN.py:574-575
+        if ((rc = reset_on_stream(e, batch, static_cast<hipStream_t>(stream)))) return rc;  // CRN.py:574-575
     } else {
         if (e->B != batch) return fail(e, SE_ERR_STATE, "flag=True with batch %d but the carried state holds %d streams", batch, e->B);
         if ((rc = ensure_ready(e))) return rc;
