@@ -68,6 +68,7 @@ struct se_engine {
     std::map<std::string, std::vector<int64_t>> shapes;
     bool weights_ready = false;
     size_t conv_lds_budget = 48 * 1024;
+    bool gru_direct = false;  // SE_GRU_DIRECT=1: always use the register-streaming step kernel
 
     // constant tables
     DevBuf window, env, tw;
@@ -454,7 +455,10 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
             GruStepArgs g{e->gi.p + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
                           e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
             ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
-            hipLaunchKernelGGL(k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
+            const dim3 grid((H + 15) / 16, (B + 31) / 32);
+            if (H == 512 && !e->gru_direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
+            else if (H == 128 && !e->gru_direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
+            else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
             e->hcur[l] = hc ^ 1;
         }
         HIPCHECK(e, hipGetLastError());
@@ -564,6 +568,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     e->plan.npass = fft_plan(cfg->n_fft / 2, e->plan.radices);
     if (!e->plan.npass || e->plan.npass > kMaxRadices) return bail(SE_ERR_ARG, "n_fft must factor into 2s and 5s");
     if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
+    if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0;
     if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
     // tables: hamming(win) centred in n_fft (torch.stft), twiddles, overlap-add envelope
     const int N = e->N, T = e->T, hop = cfg->hop, K = e->K;
@@ -592,6 +597,8 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
 #undef SE_CONV_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
     *out = e;
     return SE_OK;
 }
