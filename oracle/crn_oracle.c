@@ -639,3 +639,11 @@ void crn_oracle_decompress_cirm(const float *m_in, long n, float *out) { /* util
         out[i] = -10.0f * logf((10.0f - m) / (10.0f + m));
     }
 }
+
+/* thread control for the cpu_baseline leg of bench.py (returns the thread count in effect) */
+#ifdef _OPENMP
+#include <omp.h>
+int crn_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int crn_oracle_set_threads(int n) { (void)n; return 1; }
+#endif

@@ -61,6 +61,8 @@ def lib():
         L.crn_oracle_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
         L.crn_oracle_state.restype = fp
         L.crn_oracle_state.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
+        L.crn_oracle_set_threads.restype = C.c_int
+        L.crn_oracle_set_threads.argtypes = [C.c_int]
         L.crn_oracle_si_snr.restype = C.c_float
         L.crn_oracle_si_snr.argtypes = [fp, fp, C.c_int, C.c_long, C.POINTER(C.c_int64)]
         _lib = L
