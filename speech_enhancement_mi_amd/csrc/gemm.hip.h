@@ -104,6 +104,138 @@ __global__ __launch_bounds__(256) void k_gemm_tn(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16x6").  Each fp32 operand is split into three bf16 planes
+// x = hi + mid + lo (24 mantissa bits, each difference exact in fp32) and the product is formed from the six
+// leading cross terms hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid, accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Dropped terms are <= 2^-24 relative, i.e. below fp32 rounding: measured error vs an
+// fp64 GEMM 2.6e-8 (a plain fp32 k-ordered chain: 2.6e-7).  Six bf16 MFMAs (6 x 32 cycles, K = 16) replace eight
+// fp32 MFMAs (8 x 64 cycles): 2.7x fewer matrix-pipe cycles, which is what bounds this path (and the chip holds
+// a low clock under sustained fp32 MFMA load).
+// W is pre-split on the host (three [N][K] bf16 planes); A is split on the fly while it is staged into LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kXLd = kGemmKC + 8;  // bf16 elements per LDS row (80 B: conflict-free 16-B fragment reads)
+
+struct GemmX6Args {
+    const float *A;
+    const __bf16 *Wp;  // [3][N][K]
+    const float *bias;
+    float *C;
+    int M, N, K;
+    long lda, ldc;
+    int relu;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
+    __shared__ __align__(16) __bf16 Ap[3][kGemmBM * kXLd];
+    __shared__ __align__(16) __bf16 Wp[3][kGemmBN * kXLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    f32x4 qa[4];
+    uint4 qw[6];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
+            const int row = min(m0 + r, a.M - 1), k = min(k0 + kq, a.K - 4);
+            qa[it] = *reinterpret_cast<const f32x4 *>(a.A + (long)row * a.lda + k);
+        }
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
+            const int row = min(n0 + r, a.N - 1), k = min(k0 + q, a.K - 8);
+            qw[it] = *reinterpret_cast<const uint4 *>(a.Wp + ((long)plane * a.N + row) * a.K + k);
+        }
+    };
+    issue(0);
+    for (int k0 = 0; k0 < a.K; k0 += kGemmKC) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
+            const bool ok = (m0 + r < a.M) && (k0 + kq < a.K);
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                __bf16 hh, mm, ll;
+                split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
+                h[e] = hh; m[e] = mm; l[e] = ll;
+            }
+            *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
+            *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
+            *reinterpret_cast<bf16x4 *>(&Ap[2][r * kXLd + kq]) = l;
+        }
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
+            const bool ok = (n0 + r < a.N) && (k0 + q < a.K);
+            *reinterpret_cast<uint4 *>(&Wp[plane][r * kXLd + q]) = ok ? qw[it] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        if (k0 + kGemmKC < a.K) issue(k0 + kGemmKC);  // next chunk in flight during the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < kGemmKC; ks += 16) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    fa[i][p] = *reinterpret_cast<const bf16x8 *>(&Ap[p][(wm + i * 32 + l31) * kXLd + ks + half * 8]);
+                    fb[i][p] = *reinterpret_cast<const bf16x8 *>(&Wp[p][(wn + i * 32 + l31) * kXLd + ks + half * 8]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
+                    acc[i][j] = c;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = n0 + wn + j * 32 + l31;
+            if (n >= a.N) continue;
+            const float bs = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) {
+                    float v = acc[i][j][r] + bs;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.C[(long)m * a.ldc + n] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One GRU time step for all streams (torch.nn.GRU cell, gate order r,z,n; reference CRN.py:269):
 //   gh = h_prev W_hh^T + b_hh ;  r = s(gi_r + gh_r) ; z = s(gi_z + gh_z) ; n = tanh(gi_n + r * gh_n)
 //   h  = (1 - z) n + z h_prev

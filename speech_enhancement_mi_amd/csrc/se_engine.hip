@@ -77,6 +77,8 @@ struct se_engine {
     // weights
     Level lv[SE_MAX_LEVELS];  // enc i at lv[i]; decoder j at lv[j] (dec_* members)
     DevBuf wih[4], whh[4], bih[4], bhh[4], fcw, fcb, gnw, gnb;
+    DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
+    int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
 
     // state + activations for B streams
     int B = 0;
@@ -169,6 +171,36 @@ struct ProfScope {  // brackets one launch with two events when profiling is on
         if (idx >= 0) (void)hipEventRecord(e->prof_recs[idx].b, st);
     }
 };
+
+uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// three bf16 planes (hi, mid, lo) of a [rows][cols] fp32 matrix -> device buffer of 3*rows*cols uint16
+int upload_split3(se_engine *e, DevBuf &b, const std::vector<float> &w) {
+    const size_t n = w.size();
+    std::vector<uint16_t> planes(3 * n);
+    for (size_t i = 0; i < n; i++) {
+        const float x = w[i];
+        const uint16_t h = bf16_rne(x);
+        const float r1 = x - bf16_to_f32(h);
+        const uint16_t m = bf16_rne(r1);
+        const float r2 = r1 - bf16_to_f32(m);
+        planes[i] = h; planes[n + i] = m; planes[2 * n + i] = bf16_rne(r2);
+    }
+    int rc = dev_alloc(e, b, (3 * n + 1) / 2);
+    if (rc) return rc;
+    HIPCHECK(e, hipMemcpy(b.p, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return 0;
+}
 
 std::string canon(const char *key) {
     std::string k(key);
@@ -347,6 +379,7 @@ int prepare_weights(se_engine *e) {
         auto *d = param(e, "gru.sequence_model.bias_hh_l" + s, 3 * (size_t)H);
         if (!a || !b || !c || !d) return SE_ERR_PARAM_MISSING;
         int rc;
+        if ((rc = upload_split3(e, e->wih_x[l], *a))) return rc;
         if ((rc = dev_upload(e, e->wih[l], *a)) || (rc = dev_upload(e, e->whh[l], *b)) ||
             (rc = dev_upload(e, e->bih[l], *c)) || (rc = dev_upload(e, e->bhh[l], *d)))
             return rc;
@@ -358,6 +391,7 @@ int prepare_weights(se_engine *e) {
         auto *d = param(e, "gru.norm.bias", D);
         if (!a || !b || !c || !d) return SE_ERR_PARAM_MISSING;
         int rc;
+        if ((rc = upload_split3(e, e->fcw_x, *a))) return rc;
         if ((rc = dev_upload(e, e->fcw, *a)) || (rc = dev_upload(e, e->fcb, *b)) || (rc = dev_upload(e, e->gnw, *c)) ||
             (rc = dev_upload(e, e->gnb, *d)))
             return rc;
@@ -390,7 +424,15 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
 }
 
 int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw, const float *bias, float *C, long ldc,
-                int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label) {
+                int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label, const float *Wx = nullptr) {
+    dim3 ggrid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
+    if (Wx && e->gemm_mode == 6 && Kd % 8 == 0 && Kd >= 8 && lda % 4 == 0 && ldw == Kd) {
+        ProfScope ps(e, "k_gemm_bf16x6", label, 2.0 * Mr * Nc * Kd, st);
+        GemmX6Args g{A, reinterpret_cast<const __bf16 *>(Wx), bias, C, Mr, Nc, Kd, lda, ldc, relu};
+        hipLaunchKernelGGL(k_gemm_bf16x6, ggrid, dim3(256), 0, st, g);
+        HIPCHECK(e, hipGetLastError());
+        return 0;
+    }
     ProfScope ps(e, "k_gemm_tn", label, 2.0 * Mr * Nc * Kd, st);
     if (Kd % 4 || Kd < 4 || lda % 4 || ldw % 4) return fail(e, SE_ERR_ARG, "GEMM inner dimension %d must be a multiple of 4", Kd);
     GemmArgs g{A, W, bias, C, Mr, Nc, Kd, lda, ldw, ldc, relu};
@@ -448,7 +490,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     const float *layer_in = e->gru_in.p;
     long in_dim = D;
     for (int l = 0; l < e->NL; l++) {
-        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc;
+        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
         float *seq = e->seq[l & 1].p;
         for (int t = 0; t < T; t++) {
             const int hc = e->hcur[l];
@@ -465,7 +507,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
         layer_in = seq;
         in_dim = H;
     }
-    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st, "gru_fc"))) return rc;
+    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st, "gru_fc", e->fcw_x.p))) return rc;
     if ((rc = launch_gln(e, e->fc_out.p, e->dec_in.p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st))) return rc;
     // decoder (CRN.py:483-489)
     const float *x = e->dec_in.p;
@@ -569,6 +611,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (!e->plan.npass || e->plan.npass > kMaxRadices) return bail(SE_ERR_ARG, "n_fft must factor into 2s and 5s");
     if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
     if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0;
+    if (const char *s = getenv("SE_GEMM_MODE")) e->gemm_mode = atoi(s);
     if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
     // tables: hamming(win) centred in n_fft (torch.stft), twiddles, overlap-add envelope
     const int N = e->N, T = e->T, hop = cfg->hop, K = e->K;
@@ -608,10 +651,10 @@ void se_destroy(se_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
-                         &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
+                         &e->fcw_x, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
     for (DevBuf *b : singles) dev_free(*b);
     for (int i = 0; i < 4; i++) {
-        dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]);
+        dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
         dev_free(e->hbuf[i][0]); dev_free(e->hbuf[i][1]);
     }
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
