@@ -1,0 +1,189 @@
+// conv_x6.hip.h - the implicit-GEMM convolution of conv_igemm.hip.h on the bf16 matrix cores with fp32 accuracy.
+//
+// Same GEMM view, tiling, gather plan, epilogue and statistics as k_conv_igemm; what changes is the arithmetic:
+// every fp32 operand is split into three bf16 planes (x = hi + mid + lo, 24 mantissa bits) and each product is
+// formed from the six leading cross terms with v_mfma_f32_32x32x16_bf16 (see gemm.hip.h, k_gemm_bf16x6: measured
+// error 2.6e-8 vs 2.6e-7 for a k-ordered fp32 chain).  6 x 32 matrix-pipe cycles per 16-deep K step replace
+// 8 x 64 cycles of v_mfma_f32_32x32x2_f32.
+//   K step  = 2 taps x 8 input channels  (lane half h of the MFMA operand selects the tap, j the channel)
+//   patch   = LDS [plane 3][row][col][8 ch] bf16: one 16-B ds_read_b128 per B fragment at lane_base + tap offset
+//   weights = pre-split on the host as [chunk][tap pair][plane][Cout tile][32 co][16 k]: one coalesced 1-KB
+//             global load per A fragment straight to registers (prefetched one pair ahead; no LDS weight slab,
+//             so the LDS holds three patch planes instead)
+//   staging = each thread owns up to 4 patch positions x 8 channels; fp32 values are prefetched into registers
+//             during the previous chunk's MFMAs, split and written as three 16-B LDS stores per position.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.hip.h"
+#include "gemm.hip.h"
+
+namespace se {
+
+constexpr int kX6PosPerThread = 4;  // patch positions (row, col) per thread: R*St <= 1024 (host-checked)
+
+struct ConvX6Args {
+    ConvArgs c;        // geometry, x / xprev / bias / y / stats exactly as for k_conv_igemm (c.w unused, c.CC == 8)
+    const uint4 *wx;   // [nchunk][npair][3][MT][64] fragments of 16 B
+};
+
+__device__ __forceinline__ uint4 pack_bf16x8(const __bf16 (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = v[i];
+    return __builtin_bit_cast(uint4, t);
+}
+
+template <int NTAP, int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
+    extern __shared__ __align__(16) uint4 planes[];  // [3][Npos]
+    const ConvArgs &a = xa.c;
+    constexpr int NPAIR = (NTAP + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int P = a.T * a.FP;
+    const int p0 = blockIdx.x * a.tiles_per_wg * 32;
+    if (p0 >= P) return;
+    const int p1 = min(P, p0 + a.tiles_per_wg * 32);
+    const int ta = p0 / a.FP, tb = (p1 - 1) / a.FP;
+    const int RT = tb - ta + 1;
+    const int R = a.grouped ? a.ngroup * RT : RT + (a.ngroup - 1) * a.dil;
+    const int St = a.St, Npos = R * St;
+    const int MT = a.CoPad >> 5, NCG = 4 / MT;
+    const int mt = wave % MT, cg = wave / MT;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int lane_base[NT], pos_t[NT], pos_m[NT];
+    bool lane_ok[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int p = p0 + (cg + i * NCG) * 32 + l31;
+        lane_ok[i] = p < p1;
+        const int pc = lane_ok[i] ? p : (p1 - 1);
+        const int t = pc / a.FP, m = pc - t * a.FP;
+        pos_t[i] = t;
+        pos_m[i] = m;
+        lane_base[i] = (t - ta) * St + a.s * m;
+    }
+    int toffL[NPAIR];  // per lane half: position offset of tap 2*pair + half
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; pr++) {
+        const int tp = min(2 * pr + half, NTAP - 1);  // a padded (zero-weight) tap reads any valid position
+        toffL[pr] = a.rowgrp[tp] * (a.grouped ? RT : a.dil) * St + a.coloff[tp];
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    const long xs_c = (long)a.T * a.Fi;
+    const float *xb = a.x + (long)b * a.Ci * xs_c;
+    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : xb;
+
+    // ---- gather plan over patch positions pe = tid + 256*k ----
+    int goff[kX6PosPerThread];
+    unsigned okmask = 0, histmask = 0;
+    {
+        const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
+#pragma unroll
+        for (int k = 0; k < kX6PosPerThread; k++) {
+            const int pe = min(tid + 256 * k, Npos - 1);
+            const int r = pe / St, col = pe - r * St;
+            const int g = NGp > 1 ? r / RTp : 0, j = r - g * RTp;
+            const int ts = ta + a.tlo_off + g * a.dil + j;
+            const int fi = col - a.colpad;
+            const bool hist = ts < 0;
+            const bool ok = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
+            const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1), fic = min(max(fi, 0), a.Fi - 1);
+            goff[k] = tsc * a.Fi + fic;
+            okmask |= (ok ? 1u : 0u) << k;
+            histmask |= (hist ? 1u : 0u) << k;
+        }
+    }
+    float pv[kX6PosPerThread][8];
+    auto issue_loads = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < kX6PosPerThread; k++) {
+            const float *base = ((histmask >> k) & 1u) ? xpb : xb;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = min(ch * 8 + c, a.Ci - 1);
+                pv[k][c] = base[(long)ci * xs_c + goff[k]];  // raw; masked at the LDS write
+            }
+        }
+    };
+    issue_loads(0);
+    const uint4 *wxw = xa.wx + (long)mt * 64 + l31 * 2 + half;  // + (((ch*NPAIR + pr)*3 + plane)*MT) * 64
+    const long wx_plane = (long)MT * 64, wx_pair = 3 * wx_plane, wx_chunk = NPAIR * wx_pair;
+
+    for (int ch = 0; ch < a.nchunk; ch++) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int k = 0; k < kX6PosPerThread; k++) {
+            const int pe = tid + 256 * k;
+            if (pe < Npos) {
+                const bool ok = (okmask >> k) & 1u;
+                __bf16 h[8], m[8], l[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) split3((ok && ch * 8 + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
+                planes[pe] = pack_bf16x8(h);
+                planes[Npos + pe] = pack_bf16x8(m);
+                planes[2 * Npos + pe] = pack_bf16x8(l);
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < a.nchunk) issue_loads(ch + 1);  // in flight during the MFMAs below
+        const uint4 *wc = wxw + ch * wx_chunk;
+        uint4 fa_n[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) fa_n[p] = wc[p * wx_plane];
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; pr++) {
+            bf16x8 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) fa[p] = __builtin_bit_cast(bf16x8, fa_n[p]);
+            if (pr + 1 < NPAIR) {
+#pragma unroll
+                for (int p = 0; p < 3; p++) fa_n[p] = wc[(pr + 1) * wx_pair + p * wx_plane];
+            }
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int pos = lane_base[i] + toffL[pr];
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[Npos + pos]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * Npos + pos]);
+                f32x16 c = acc[i];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b1, c, 0, 0, 0);  // mid*mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b2, c, 0, 0, 0);  // hi*lo
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], b0, c, 0, 0, 0);  // lo*hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b1, c, 0, 0, 0);  // hi*mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b0, c, 0, 0, 0);  // mid*hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b0, c, 0, 0, 0);  // hi*hi
+                acc[i] = c;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: bias, ReLU, store [B][Co][T][Fy], partial norm statistics (identical to k_conv_igemm) ----
+    const long ys_c = (long)a.T * a.Fy;
+    float *yb = a.y + (long)b * a.Co * ys_c;
+    float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        if (!lane_ok[i]) continue;
+        float *yp = yb + (long)pos_t[i] * a.Fy + a.os * pos_m[i] + a.oo;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < a.Co) {
+                float v = acc[i][r] + a.bias[co];
+                if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
+                yp[co * ys_c] = v;
+                if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
+            }
+        }
+    }
+    if (a.stats) conv_stats_store(a, ssum, ssq, reinterpret_cast<float *>(planes), b);
+}
+
+}  // namespace se

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <array>
 #include <map>
 #include <string>
@@ -23,6 +24,7 @@
 
 #include "../../include/se_engine.h"
 #include "conv_igemm.hip.h"
+#include "conv_x6.hip.h"
 #include "fft_lds.h"
 #include "gemm.hip.h"
 #include "norm.hip.h"
@@ -46,6 +48,8 @@ struct ConvPlan {
     size_t lds = 0;
     DevBuf w, bias;
     bool active = false;
+    bool x6 = false;  // bf16x6 kernel (k_conv_x6) instead of the fp32-MFMA k_conv_igemm
+    DevBuf wx;
     double flops = 0;  // algorithmic FLOPs per stream per launch (SURVEY.md 8d accounting)
 };
 
@@ -79,6 +83,7 @@ struct se_engine {
     DevBuf wih[4], whh[4], bih[4], bhh[4], fcw, fcb, gnw, gnb;
     DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
+    int conv_mode = 6;        // SE_CONV_MODE: 0 = fp32 MFMA (k_conv_igemm), 6 = bf16x6 where Cin % 8 == 0 (default)
 
     // state + activations for B streams
     int B = 0;
@@ -257,6 +262,53 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int MT = CoPad / 32;
     if (MT == 3) return fail(e, SE_ERR_ARG, "conv output channels %d need 3 row tiles (unsupported)", Co);
     const int NCG = 4 / MT, NTmax = 4;
+    if (e->conv_mode == 6 && Ci % 8 == 0) {  // ---- bf16x6 path: K step = 2 taps x 8 channels ----
+        int tpw = 0, n_wg = 0, NT = 0, Rmax = 0, grouped = 0;
+        for (int ntmax = NTmax; ntmax >= 1; ntmax--) {
+            n_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
+            tpw = (tiles + n_wg - 1) / n_wg;
+            NT = (tpw + NCG - 1) / NCG;
+            int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
+            if (rows_pos > T) rows_pos = T;
+            grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+            Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
+            if ((size_t)Rmax * St <= 256 * kX6PosPerThread) break;
+            NT = 0;
+        }
+        if (NT > 0) {
+            const int npair = (ntap + 1) / 2, nchunk = Ci / 8;
+            ConvArgs &a = pl.a;
+            a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
+            a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
+            a.ntap = ntap; a.CC = 8; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+            a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+            for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
+            pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true;
+            pl.lds = std::max<size_t>((size_t)3 * Rmax * St * 16, 64);
+            // weights: [chunk][pair][plane][mtile][co 32][k 16], k = half*8 + c <-> (tap 2*pair+half, channel chunk*8+c)
+            std::vector<uint16_t> wx((size_t)nchunk * npair * 3 * MT * 32 * 16, 0);
+            for (int ch = 0; ch < nchunk; ch++)
+                for (int pr = 0; pr < npair; pr++)
+                    for (int m = 0; m < MT; m++)
+                        for (int r = 0; r < 32; r++)
+                            for (int k = 0; k < 16; k++) {
+                                const int tp = 2 * pr + k / 8, ci = ch * 8 + k % 8, co = m * 32 + r;
+                                if (tp >= ntap || co >= Co) continue;
+                                const float x = wsel(ci, co, taps[tp][0], taps[tp][1]);
+                                const uint16_t h = bf16_rne(x);
+                                const float r1 = x - bf16_to_f32(h);
+                                const uint16_t md = bf16_rne(r1);
+                                const float r2 = r1 - bf16_to_f32(md);
+                                const uint16_t parts[3] = {h, md, bf16_rne(r2)};
+                                for (int pln = 0; pln < 3; pln++)
+                                    wx[(((((size_t)ch * npair + pr) * 3 + pln) * MT + m) * 32 + r) * 16 + k] = parts[pln];
+                            }
+            int rc = dev_alloc(e, pl.wx, (wx.size() + 1) / 2);
+            if (rc) return rc;
+            HIPCHECK(e, hipMemcpy(pl.wx.p, wx.data(), wx.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            return dev_upload(e, pl.bias, bias);
+        }
+    }
     const int n_wg = (tiles + NCG * NTmax - 1) / (NCG * NTmax);
     const int tpw = (tiles + n_wg - 1) / n_wg;
     const int NT = (tpw + NCG - 1) / NCG;
@@ -404,11 +456,25 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
                 float *stats = nullptr, int nslot = 0, int slot0 = 0, int stats_lo = 0, int stats_hi = 0) {
     if (!pl.active) return 0;
     // algorithmic MACs of this launch as SURVEY.md 8d counts them are attributed by the caller via pl.flops
-    ProfScope ps(e, "k_conv_igemm", label, pl.flops * e->B, st);
+    ProfScope ps(e, pl.x6 ? "k_conv_x6" : (pl.NT == 0 ? "k_conv_small" : "k_conv_igemm"), label, pl.flops * e->B, st);
     ConvArgs a = pl.a;
     a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p;
     a.stats = stats; a.stats_nslot = nslot; a.stats_slot0 = slot0; a.stats_lo = stats_lo; a.stats_hi = stats_hi;
     dim3 grid(pl.grid_x, e->B);
+    if (pl.x6) {
+        ConvX6Args xa{a, reinterpret_cast<const uint4 *>(pl.wx.p)};
+#define SE_X6_CASE(NTAP_, NT_) \
+    case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_>), grid, dim3(256), pl.lds, st, xa); break;
+#define SE_X6_TAPS(NTAP_) SE_X6_CASE(NTAP_, 1) SE_X6_CASE(NTAP_, 2) SE_X6_CASE(NTAP_, 3) SE_X6_CASE(NTAP_, 4)
+        switch (a.ntap * 8 + pl.NT) {
+            SE_X6_TAPS(15) SE_X6_TAPS(9) SE_X6_TAPS(6) SE_X6_TAPS(1)
+            default: return fail(e, SE_ERR_ARG, "no x6 conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
+        }
+#undef SE_X6_TAPS
+#undef SE_X6_CASE
+        HIPCHECK(e, hipGetLastError());
+        return 0;
+    }
 #define SE_CONV_CASE(NTAP_, NT_) \
     case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
 #define SE_CONV_TAPS(NTAP_) SE_CONV_CASE(NTAP_, 1) SE_CONV_CASE(NTAP_, 2) SE_CONV_CASE(NTAP_, 3) SE_CONV_CASE(NTAP_, 4) \
@@ -612,6 +678,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
     if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0;
     if (const char *s = getenv("SE_GEMM_MODE")) e->gemm_mode = atoi(s);
+    if (const char *s = getenv("SE_CONV_MODE")) e->conv_mode = atoi(s);
     if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
     // tables: hamming(win) centred in n_fft (torch.stft), twiddles, overlap-add envelope
     const int N = e->N, T = e->T, hop = cfg->hop, K = e->K;
@@ -640,6 +707,13 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
 #undef SE_CONV_ATTR
+#define SE_X6_ATTR(NTAP_)                                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SE_X6_ATTR(15) SE_X6_ATTR(9) SE_X6_ATTR(6) SE_X6_ATTR(1)
+#undef SE_X6_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
     *out = e;
@@ -659,7 +733,7 @@ void se_destroy(se_engine *e) {
     }
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
         Level &l = e->lv[i];
-        for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip}) { dev_free(p->w); dev_free(p->bias); }
+        for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
         for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
         dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
