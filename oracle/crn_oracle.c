@@ -30,12 +30,15 @@ typedef struct {
     int channels[MAXL];
     int num_freqs, hidden, num_layers, num_inputs, kernel_size;
     int n_fft, win, hop, segment_length;
+    int variant; /* 0 = CRN.py (ReLU), 1 = CRN_ELU.py (ELU, gated 1x1, 3 preconv blocks, atan2), 2 = distillation_crn.py student
+                    (as 1 but arctan phase and gLN denominator sqrt(var)+eps) */
 } crn_cfg;
 
 typedef struct {
     float *w, *b;   /* conv weight / bias */
     float *nw, *nb; /* norm affine */
     float *mw, *mb, *mnw, *mnb, *rw, *rb; /* decoder: residualmask, residualnorm, residual */
+    float *tw, *tb, *gw, *gb;             /* CRN_ELU encoder/preconv: conv_trans, conv_gated (1x1) */
 } layer_w;
 
 typedef struct crn_oracle {
@@ -43,14 +46,15 @@ typedef struct crn_oracle {
     int F[MAXL + 1];   /* freq size per encoder level: F[0]=num_freqs, F[i+1]=conv out */
     int Cin[MAXL + 1]; /* channels per level: Cin[0]=2M-1 */
     int T, D;
-    layer_w enc[MAXL], dec[MAXL];
+    layer_w enc[MAXL], dec[MAXL], pre[3];
+    float *pbuf[3]; /* preconv time buffers [B,Cin0,F0,4] (CRN_ELU.py:335-340) */
     float *wih[4], *whh[4], *bih[4], *bhh[4], *fcw, *fcb, *gnw, *gnb;
     /* streaming state (CRN.py:319-337, 254/281) */
     int B;
     float *buf[MAXL]; /* [B,Cin,F,2d] */
     float *h;         /* [layers,B,H] */
     /* taps of the last forward() */
-    float *tap_feat, *tap_enc[MAXL], *tap_gru, *tap_dec[MAXL];
+    float *tap_feat, *tap_enc[MAXL], *tap_gru, *tap_dec[MAXL], *tap_pre;
     double *tw_c, *tw_s; /* n_fft twiddles */
     float *window;       /* n_fft, hamming(win) centred */
     char err[256];
@@ -102,6 +106,8 @@ static void free_state(crn_oracle *o) {
         free(o->tap_enc[i]); o->tap_enc[i] = NULL;
         free(o->tap_dec[i]); o->tap_dec[i] = NULL;
     }
+    for (int i = 0; i < 3; i++) { free(o->pbuf[i]); o->pbuf[i] = NULL; }
+    free(o->tap_pre); o->tap_pre = NULL;
     free(o->h); o->h = NULL;
     free(o->tap_feat); o->tap_feat = NULL;
     free(o->tap_gru); o->tap_gru = NULL;
@@ -111,8 +117,10 @@ void crn_oracle_destroy(crn_oracle *o) {
     if (!o) return;
     free_state(o);
     for (int i = 0; i < MAXL; i++) {
-        layer_w *ls[2] = {&o->enc[i], &o->dec[i]};
-        for (int k = 0; k < 2; k++) {
+        layer_w *ls[3] = {&o->enc[i], &o->dec[i], &o->pre[i < 3 ? i : 0]};
+        for (int k = 0; k < (i < 3 ? 3 : 2); k++) {
+            free(ls[k]->tw); free(ls[k]->tb); free(ls[k]->gw); free(ls[k]->gb);
+            ls[k]->tw = ls[k]->tb = ls[k]->gw = ls[k]->gb = NULL;
             free(ls[k]->w); free(ls[k]->b); free(ls[k]->nw); free(ls[k]->nb); free(ls[k]->mw);
             free(ls[k]->mb); free(ls[k]->mnw); free(ls[k]->mnb); free(ls[k]->rw); free(ls[k]->rb);
         }
@@ -140,9 +148,24 @@ int crn_oracle_load(crn_oracle *o, const char *key, const float *data, const int
     for (int i = 0; i < ndim; i++) n *= shape[i];
     int L = o->c.num_levels, H = o->c.hidden, idx;
     char rest[128];
-    if (sscanf(key, "convlist.%d.%127s", &idx, rest) == 2 && idx >= 0 && idx < L) {
+    if (sscanf(key, "preconvlist.%d.%127s", &idx, rest) == 2 && idx >= 0 && idx < 3) {
+        layer_w *l = &o->pre[idx];
+        long c = o->Cin[0];
+        if (!strcmp(rest, "conv.weight") || !strcmp(rest, "net.0.weight")) return set_param(&l->w, data, n, c * c * 25, o, key);
+        if (!strcmp(rest, "conv.bias") || !strcmp(rest, "net.0.bias")) return set_param(&l->b, data, n, c, o, key);
+        if (!strcmp(rest, "conv_trans.weight")) return set_param(&l->tw, data, n, c * c, o, key);
+        if (!strcmp(rest, "conv_trans.bias")) return set_param(&l->tb, data, n, c, o, key);
+        if (!strcmp(rest, "conv_gated.weight")) return set_param(&l->gw, data, n, c * c, o, key);
+        if (!strcmp(rest, "conv_gated.bias")) return set_param(&l->gb, data, n, c, o, key);
+        if (!strcmp(rest, "norm.weight")) return set_param(&l->nw, data, n, c, o, key);
+        if (!strcmp(rest, "norm.bias")) return set_param(&l->nb, data, n, c, o, key);
+    } else if (sscanf(key, "convlist.%d.%127s", &idx, rest) == 2 && idx >= 0 && idx < L) {
         layer_w *l = &o->enc[idx];
         long ci = o->Cin[idx], co = o->Cin[idx + 1];
+        if (!strcmp(rest, "conv_trans.weight")) return set_param(&l->tw, data, n, co * co, o, key);
+        if (!strcmp(rest, "conv_trans.bias")) return set_param(&l->tb, data, n, co, o, key);
+        if (!strcmp(rest, "conv_gated.weight")) return set_param(&l->gw, data, n, co * co, o, key);
+        if (!strcmp(rest, "conv_gated.bias")) return set_param(&l->gb, data, n, co, o, key);
         if (!strcmp(rest, "conv.weight") || !strcmp(rest, "net.0.weight")) return set_param(&l->w, data, n, co * ci * 15, o, key);
         if (!strcmp(rest, "conv.bias") || !strcmp(rest, "net.0.bias")) return set_param(&l->b, data, n, co, o, key);
         if (!strcmp(rest, "norm.weight")) return set_param(&l->nw, data, n, co, o, key);
@@ -190,6 +213,10 @@ void crn_oracle_reset(crn_oracle *o, int B) {
         int co = lvl == 0 ? 2 : o->Cin[lvl];
         o->tap_dec[i] = (float *)xcalloc((size_t)B * co * o->F[lvl] * T, sizeof(float));
     }
+    if (o->c.variant) {
+        for (int i = 0; i < 3; i++) o->pbuf[i] = (float *)xcalloc((size_t)B * o->Cin[0] * o->F[0] * 4, sizeof(float));
+        o->tap_pre = (float *)xcalloc((size_t)B * o->Cin[0] * o->F[0] * T, sizeof(float));
+    }
     o->h = (float *)xcalloc((size_t)o->c.num_layers * B * o->c.hidden, sizeof(float));
     o->tap_feat = (float *)xcalloc((size_t)B * o->Cin[0] * o->F[0] * T, sizeof(float));
     o->tap_gru = (float *)xcalloc((size_t)B * o->D * T, sizeof(float));
@@ -218,6 +245,9 @@ void crn_oracle_stft(crn_oracle *o, const float *x, int n, float *out) {
                     im -= fr[i] * o->tw_s[k];
                 }
                 size_t off = (((size_t)s * F + f) * T + t) * 2;
+                /* a real-input FFT returns exactly +0 imaginary parts at DC and Nyquist (torch/pocketfft do); CRN_ELU's
+                 * atan2 (CRN_ELU.py:370) turns a -1e-17 there into a 2*pi phase flip, so the restatement must too */
+                if (f == 0 || 2 * f == N) im = 0.0;
                 out[off] = (float)re;
                 out[off + 1] = (float)im;
             }
@@ -257,6 +287,7 @@ void crn_oracle_istft(crn_oracle *o, const float *X, int n, float *y) {
 
 /* ---- A6: GlobalLayerNorm(time=False) forward, CRN.py:135-149.  x [B, n] per sample; affine index
  * = (i / inner) % dim, covering both [1,C,1,1] (inner=F*T, dim=C) and last=True [1,1,1,D] (inner=1). ---- */
+static int g_gln_eps_outside_only = 0; /* student: sqrt(var)+eps (distillation_crn.py:51); else sqrt(var+eps)+eps (CRN.py:149) */
 static void gln(float *x, int B, long n, const float *w, const float *b, long inner, long dim) {
 #pragma omp parallel for schedule(static)
     for (int s = 0; s < B; s++) {
@@ -267,7 +298,7 @@ static void gln(float *x, int B, long n, const float *w, const float *b, long in
         double sq = 0;
         for (long i = 0; i < n; i++) { float d = p[i] - mean; sq += (double)(d * d); }
         float var = (float)(sq / n);
-        float den = sqrtf(var + EPS) + EPS;
+        float den = (g_gln_eps_outside_only ? sqrtf(var) : sqrtf(var + EPS)) + EPS;
         for (long i = 0; i < n; i++) {
             long c = (i / inner) % dim;
             p[i] = (p[i] - mean) / den * w[c] + b[c];
@@ -277,13 +308,17 @@ static void gln(float *x, int B, long n, const float *w, const float *b, long in
 
 static inline float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-/* ---- A5: TemporalConv2d.forward, CRN.py:321-338 ---- */
-static void enc_block(crn_oracle *o, int i, const float *x, float *y) {
-    int B = o->B, T = o->T, Ci = o->Cin[i], Co = o->Cin[i + 1], Fi = o->F[i], Fo = o->F[i + 1], d = 1 << i, P = 2 * d;
-    const layer_w *l = &o->enc[i];
-    float *buf = o->buf[i];
+static inline float eluf(float v) { return v > 0 ? v : (expf(v) - 1.0f); } /* nn.ELU(alpha=1) */
+
+/* ---- A5: TemporalConv2d.forward, CRN.py:321-338; CRN_ELU.py:233-247 (ELU, conv_trans * sigmoid(conv_gated)).
+ * Generic geometry: kernel (5,KT), freq stride sf, freq dilation dilf, freq pad padf, time dilation dilt, causal
+ * time buffer of P=(KT-1)*dilt columns.  Encoder: KT=3, sf=2, dilf=1, padf=2, dilt=2^i.  Preconv (CRN_ELU.py:335-340):
+ * KT=5, sf=1, dilf=fd, padf=2*fd, dilt=1. ---- */
+static void conv_block(crn_oracle *o, const layer_w *l, float *buf, const float *x, float *y, int Ci, int Co, int Fi, int Fo,
+                       int KT, int sf, int dilf, int padf, int dilt) {
+    int B = o->B, T = o->T, P = (KT - 1) * dilt, elu = o->c.variant != 0;
     int W = P + T;
-    float *inp = (float *)xcalloc((size_t)B * Ci * Fi * W, sizeof(float)); /* cat([buffer, x], -1), CRN.py:328-329 */
+    float *inp = (float *)xcalloc((size_t)B * Ci * Fi * W, sizeof(float)); /* cat([buffer, x], -1) */
     for (size_t r = 0; r < (size_t)B * Ci * Fi; r++) {
         memcpy(inp + r * W, buf + r * P, P * sizeof(float));
         memcpy(inp + r * W + P, x + r * T, T * sizeof(float));
@@ -297,34 +332,54 @@ static void enc_block(crn_oracle *o, int i, const float *x, float *y) {
                 for (int t = 0; t < T; t++) acc[t] = l->b[co];
                 for (int ci = 0; ci < Ci; ci++)
                     for (int kf = 0; kf < 5; kf++) {
-                        int fi = 2 * fo - 2 + kf; /* stride 2, pad 2 */
+                        int fi = sf * fo - padf + kf * dilf;
                         if (fi < 0 || fi >= Fi) continue;
                         const float *ir = inp + (((size_t)b * Ci + ci) * Fi + fi) * W;
-                        const float *wr = l->w + (((size_t)co * Ci + ci) * 5 + kf) * 3;
-                        for (int kt = 0; kt < 3; kt++) {
+                        const float *wr = l->w + (((size_t)co * Ci + ci) * 5 + kf) * KT;
+                        for (int kt = 0; kt < KT; kt++) {
                             float w = wr[kt];
-                            const float *iv = ir + kt * d; /* dilation (1,d), no time padding: out col t <- inp col t+kt*d */
+                            const float *iv = ir + kt * dilt;
                             for (int t = 0; t < T; t++) acc[t] += w * iv[t];
                         }
                     }
-                for (int t = 0; t < T; t++) yo[fo * T + t] = acc[t] > 0 ? acc[t] : 0; /* ReLU CRN.py:331 */
+                for (int t = 0; t < T; t++) yo[fo * T + t] = elu ? eluf(acc[t]) : (acc[t] > 0 ? acc[t] : 0);
             }
         }
     free(inp);
+    if (elu) { /* out = conv_trans(out) * sigmoid(conv_gated(out)), 1x1 convs (CRN_ELU.py:240) */
+        size_t per = (size_t)Co * Fo * T;
+        float *tmp = (float *)xcalloc((size_t)B * per, sizeof(float));
+        memcpy(tmp, y, (size_t)B * per * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; b++)
+            for (int co = 0; co < Co; co++)
+                for (int p = 0; p < Fo * T; p++) {
+                    float at = l->tb[co], ag = l->gb[co];
+                    for (int ci = 0; ci < Co; ci++) {
+                        float v = tmp[(size_t)b * per + (size_t)ci * Fo * T + p];
+                        at += l->tw[co * Co + ci] * v;
+                        ag += l->gw[co * Co + ci] * v;
+                    }
+                    y[(size_t)b * per + (size_t)co * Fo * T + p] = at * sigmoidf(ag);
+                }
+        free(tmp);
+    }
     gln(y, B, (long)Co * Fo * T, l->nw, l->nb, (long)Fo * T, Co);
     /* buffer <- last P columns of x (T > P branch, CRN.py:333-334; else-branch 335-337) */
-    for (int b = 0; b < B; b++)
-        for (int ci = 0; ci < Ci; ci++)
-            for (int f = 0; f < Fi; f++) {
-                float *br = buf + (((size_t)b * Ci + ci) * Fi + f) * P;
-                const float *xr = x + (((size_t)b * Ci + ci) * Fi + f) * T;
-                if (T > P) {
-                    for (int p = 0; p < P; p++) br[p] = xr[T - P + p];
-                } else {
-                    for (int p = 0; p < P - T; p++) br[p] = br[p + T];
-                    for (int p = 0; p < T; p++) br[P - T + p] = xr[p];
-                }
-            }
+    for (size_t r = 0; r < (size_t)B * Ci * Fi; r++) {
+        float *br = buf + r * P;
+        const float *xr = x + r * T;
+        if (T > P) {
+            for (int p = 0; p < P; p++) br[p] = xr[T - P + p];
+        } else {
+            for (int p = 0; p < P - T; p++) br[p] = br[p + T];
+            for (int p = 0; p < T; p++) br[P - T + p] = xr[p];
+        }
+    }
+}
+
+static void enc_block(crn_oracle *o, int i, const float *x, float *y) {
+    conv_block(o, &o->enc[i], o->buf[i], x, y, o->Cin[i], o->Cin[i + 1], o->F[i], o->F[i + 1], 3, 2, 1, 2, 1 << i);
 }
 
 /* ---- A8: TemporalConvTranspose2d.forward, CRN.py:379-397.  j = decoder index; dilation 2^j
@@ -359,7 +414,7 @@ static void dec_block(crn_oracle *o, int j, const float *x, const float *res, fl
                         }
                     }
                 }
-                for (int t = 0; t < T; t++) yo[fo * T + t] = acc[t] > 0 ? acc[t] : 0;
+                for (int t = 0; t < T; t++) yo[fo * T + t] = o->c.variant ? eluf(acc[t]) : (acc[t] > 0 ? acc[t] : 0);
             }
         }
     gln(tmp, B, (long)Co * Fo * T, l->nw, l->nb, (long)Fo * T, Co);
@@ -383,7 +438,7 @@ static void dec_block(crn_oracle *o, int j, const float *x, const float *res, fl
                     ar += l->rw[co * Co + ci] * v;
                 }
                 mk[(size_t)b * per + (size_t)co * Fr * T + p] = am;
-                rv[(size_t)b * per + (size_t)co * Fr * T + p] = ar > 0 ? ar : 0;
+                rv[(size_t)b * per + (size_t)co * Fr * T + p] = o->c.variant ? eluf(ar) : (ar > 0 ? ar : 0); /* CRN_ELU.py:306 */
             }
     gln(mk, B, (long)per, l->mnw, l->mnb, (long)Fr * T, Co);
     for (int b = 0; b < B; b++)
@@ -454,7 +509,7 @@ static void gru_block(crn_oracle *o, const float *x, float *y) {
 #pragma omp simd reduction(+ : a)
                 for (int q = 0; q < H; q++) a += wr[q] * hv[q];
                 a += o->fcb[k];
-                fc[((size_t)b * T + t) * D + k] = a > 0 ? a : 0;
+                fc[((size_t)b * T + t) * D + k] = o->c.variant ? eluf(a) : (a > 0 ? a : 0); /* CRN_ELU.py:365 output_activate_function */
             }
         }
     gln(fc, B, (long)T * D, o->gnw, o->gnb, 1, D);
@@ -468,6 +523,7 @@ static void gru_block(crn_oracle *o, const float *x, float *y) {
 int crn_oracle_forward(crn_oracle *o, const float *x, float *y) {
     int B = o->B, M = o->c.num_inputs, F = o->F[0], T = o->T, L = o->c.num_levels;
     if (B <= 0) { snprintf(o->err, sizeof(o->err), "forward before reset"); return -3; }
+    g_gln_eps_outside_only = o->c.variant == 2;
     size_t FT = (size_t)F * T;
     float *feat = o->tap_feat;
     /* A4 featurise, CRN.py:463-467 */
@@ -480,9 +536,19 @@ int crn_oracle_forward(crn_oracle *o, const float *x, float *y) {
         for (int m = 1; m < M; m++)
             for (size_t p = 0; p < FT; p++) {
                 const float *x0 = x + (((size_t)b * M + 0) * FT + p) * 2, *xm = x + (((size_t)b * M + m) * FT + p) * 2;
-                float a0 = atanf(x0[1] / (x0[0] + EPS) + EPS), am = atanf(xm[1] / (xm[0] + EPS) + EPS);
+                float a0, am;
+                if (o->c.variant == 1) { a0 = atan2f(x0[1], x0[0]); am = atan2f(xm[1], xm[0]); } /* CRN_ELU.py:370 */
+                else { a0 = atanf(x0[1] / (x0[0] + EPS) + EPS); am = atanf(xm[1] / (xm[0] + EPS) + EPS); }
                 feat[((size_t)b * (2 * M - 1) + M + m - 1) * FT + p] = a0 - am;
             }
+    }
+    if (o->c.variant) { /* x = m(x) + x for the three frequency-dilated 5x5 blocks (CRN_ELU.py:375-376) */
+        size_t nfe = (size_t)B * o->Cin[0] * FT;
+        for (int i = 0; i < 3; i++) {
+            int fd = 1 << i;
+            conv_block(o, &o->pre[i], o->pbuf[i], feat, o->tap_pre, o->Cin[0], o->Cin[0], F, F, 5, 1, fd, 2 * fd, 1);
+            for (size_t q = 0; q < nfe; q++) feat[q] = o->tap_pre[q] + feat[q];
+        }
     }
     const float *cur = feat;
     for (int i = 0; i < L; i++) { enc_block(o, i, cur, o->tap_enc[i]); cur = o->tap_enc[i]; }
@@ -601,6 +667,7 @@ const float *crn_oracle_tap(crn_oracle *o, const char *name, long *n) {
 const float *crn_oracle_state(crn_oracle *o, const char *name, long *n) {
     int idx;
     if (!strcmp(name, "h")) { *n = (long)o->c.num_layers * o->B * o->c.hidden; return o->h; }
+    if (sscanf(name, "pbuf%d", &idx) == 1 && idx < 3 && o->c.variant) { *n = (long)o->B * o->Cin[0] * o->F[0] * 4; return o->pbuf[idx]; }
     if (sscanf(name, "buf%d", &idx) == 1 && idx < o->c.num_levels) { *n = (long)o->B * o->Cin[idx] * o->F[idx] * 2 * (1 << idx); return o->buf[idx]; }
     *n = 0;
     return NULL;

@@ -20,7 +20,7 @@ class CrnCfg(C.Structure):
     _fields_ = [("num_levels", C.c_int), ("channels", C.c_int * MAXL), ("num_freqs", C.c_int),
                 ("hidden", C.c_int), ("num_layers", C.c_int), ("num_inputs", C.c_int),
                 ("kernel_size", C.c_int), ("n_fft", C.c_int), ("win", C.c_int), ("hop", C.c_int),
-                ("segment_length", C.c_int)]
+                ("segment_length", C.c_int), ("variant", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -81,8 +81,10 @@ class CrnOracle:
     """Mirror of reference TemporalCRN (CRN.py:404-589) on the C restatement."""
 
     def __init__(self, num_channels, num_freqs, hidden, segment_length, num_layers=1, num_inputs=3,
-                 kernel_size=3, dropout=0.0, sample_rate=16000, win_length=25, hop_length=10, n_fft=400):
+                 kernel_size=3, dropout=0.0, sample_rate=16000, win_length=25, hop_length=10, n_fft=400, variant=0):
+        """variant: 0 = CRN.py, 1 = CRN_ELU.py, 2 = distillation_crn.py (student architecture)"""
         cfg = CrnCfg()
+        cfg.variant = int(variant)
         cfg.num_levels = len(num_channels)
         for i, c in enumerate(num_channels):
             cfg.channels[i] = int(c)

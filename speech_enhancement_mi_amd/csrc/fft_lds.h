@@ -99,7 +99,11 @@ SE_HD cf2 rfft_post(const cf2 *Z, int k, int N2, const cf2 *twN) {
     const cf2 zc = Z[(N2 - k) % N2];  // conj applied below
     const cf2 e = cf2{0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};
     const cf2 o = cf2{0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x)};  // (zk - conj zc) / (2i)
-    return cadd(e, cmul(twN[k], o));
+    cf2 x = cadd(e, cmul(twN[k], o));
+    // DC and Nyquist of a real signal are real: return exactly +0 like torch/pocketfft (the arithmetic above can
+    // leave -0.0, which atan2-based phase features of CRN_ELU.py:370 turn into a 2*pi flip)
+    if (k == 0 || k == N2) x.y = 0.0f;
+    return x;
 }
 // inverse: from the onesided spectrum X (Im of DC/Nyquist ignored by the caller) build conj(Z[k]),
 // k in [0, N2), so that z = conj(FFT_N2(conj Z)) / N2 and x[2n] = Re z[n], x[2n+1] = Im z[n].

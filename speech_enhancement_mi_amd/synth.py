@@ -90,17 +90,30 @@ def make_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0) 
     return out
 
 
-def crn_param_spec(num_channels, num_freqs, hidden, num_layers=1, num_inputs=3, kernel_size=3):
-    """(key, shape) list of reference TemporalCRN.state_dict() — CRN.py:428-451 (checked against
-    the live reference module by tests/golden/make_golden.py, fixture crn_keys.json)."""
+def crn_param_spec(num_channels, num_freqs, hidden, num_layers=1, num_inputs=3, kernel_size=3, variant=0):
+    """(key, shape) list of reference TemporalCRN.state_dict() — CRN.py:428-451 (variant 0), CRN_ELU.py:335-365
+    (variant 1) and distillation_crn.py TemporalCRN (variant 2, same keys as 1); checked against the live reference
+    modules by tests/golden/make_golden.py (fixtures crn_keys.json, crn_variant_keys.json)."""
     spec = []
     L = len(num_channels)
+    c0 = 2 * num_inputs - 1
+    if variant:
+        for i in range(3):
+            p = f"preconvlist.{i}."
+            spec += [(p + "conv.weight", (c0, c0, 5, 5)), (p + "conv.bias", (c0,)),
+                     (p + "conv_trans.weight", (c0, c0, 1, 1)), (p + "conv_trans.bias", (c0,)),
+                     (p + "conv_gated.weight", (c0, c0, 1, 1)), (p + "conv_gated.bias", (c0,)),
+                     (p + "net.0.weight", (c0, c0, 5, 5)), (p + "net.0.bias", (c0,)),
+                     (p + "norm.weight", (1, c0, 1, 1)), (p + "norm.bias", (1, c0, 1, 1))]
     for i in range(L):
-        cin = (2 * num_inputs - 1) if i == 0 else num_channels[i - 1]
+        cin = c0 if i == 0 else num_channels[i - 1]
         cout = num_channels[i]
         p = f"convlist.{i}."
-        spec += [(p + "conv.weight", (cout, cin, 5, kernel_size)), (p + "conv.bias", (cout,)),
-                 (p + "net.0.weight", (cout, cin, 5, kernel_size)), (p + "net.0.bias", (cout,)),
+        spec += [(p + "conv.weight", (cout, cin, 5, kernel_size)), (p + "conv.bias", (cout,))]
+        if variant:
+            spec += [(p + "conv_trans.weight", (cout, cout, 1, 1)), (p + "conv_trans.bias", (cout,)),
+                     (p + "conv_gated.weight", (cout, cout, 1, 1)), (p + "conv_gated.bias", (cout,))]
+        spec += [(p + "net.0.weight", (cout, cin, 5, kernel_size)), (p + "net.0.bias", (cout,)),
                  (p + "norm.weight", (1, cout, 1, 1)), (p + "norm.bias", (1, cout, 1, 1))]
     for j in range(L):
         i = L - 1 - j  # deconvlist[j] mirrors encoder level i (CRN.py:438-444)

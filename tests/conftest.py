@@ -36,3 +36,17 @@ def rel_rms(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+
+STUDENT400 = dict(FULL400, num_channels=[16, 32, 64, 64], hidden=128)  # distillation_crn.py:524-525
+
+
+@pytest.fixture(scope="session")
+def vgolden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "crn_variants_golden.npz"))
+
+
+def spec_of_variant(cfg, variant):
+    from speech_enhancement_mi_amd import synth
+    return synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"],
+                                cfg["num_inputs"], cfg["kernel_size"], variant=variant)

@@ -96,12 +96,20 @@ def load_reference():
     return CRN, utility
 
 
+def load_variants():
+    """CRN_ELU.py (a12) and distillation_crn.py (a13) of the reference; call after load_reference()."""
+    import CRN_ELU  # noqa
+    import distillation_crn  # noqa
+    return CRN_ELU, distillation_crn
+
+
 def t2n(t):
     return t.detach().cpu().numpy().astype(np.float32) if t.is_floating_point() else t.detach().cpu().numpy()
 
 
 def build_ref_model(CRN, cfg, seed=0):
     model = CRN.TemporalCRN(**cfg)
+    model.eval()
     spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
     sd = synth.make_state_dict(spec, seed=seed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -213,6 +221,53 @@ def main():
     mix, _ = synth.synth_utterances(1, 5000, 3, seed=11)
     with torch.no_grad():
         out["full400_b1_L5000_out"] = t2n(model.realtime_process(torch.from_numpy(mix)))
+
+    # ---- a12 / a13: CRN_ELU.py and the distilled student architecture (distillation_crn.py TemporalCRN) ------------
+    CRN_ELU, DIST = load_variants()
+    vout = {}
+    vkeys = {}
+    STUDENT = dict(FULL400, num_channels=[16, 32, 64, 64], hidden=128)  # distillation_crn.py:524-525
+    for tag, mod, cfg, B, L, cont in (("elu_tiny", CRN_ELU, TINY, 2, 8000, 4800), ("elu_full400", CRN_ELU, FULL400, 2, 6400, 0),
+                                      ("student_tiny", DIST, TINY, 2, 8000, 4800), ("student_full400", DIST, STUDENT, 2, 6400, 0)):
+        model, spec, sd = build_ref_model(mod, cfg, seed=0)
+        vkeys[tag] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        mix, _ = synth.synth_utterances(B, L + cont, cfg["num_inputs"], seed=7)
+        mix_t = torch.from_numpy(mix)
+        stages = {}
+        hooks = []
+        if "tiny" in tag:
+            def grab(name):
+                def f(m_, i_, o_):
+                    o0 = o_[0] if isinstance(o_, tuple) else o_
+                    stages.setdefault(name, []).append(t2n(o0))
+                return f
+            for i, m_ in enumerate(model.preconvlist):
+                hooks.append(m_.register_forward_hook(grab(f"pre{i}")))
+            for i, m_ in enumerate(model.convlist):
+                hooks.append(m_.register_forward_hook(grab(f"enc{i}")))
+            for i, m_ in enumerate(model.deconvlist):
+                hooks.append(m_.register_forward_hook(grab(f"dec{i}")))
+            hooks.append(model.gru.register_forward_hook(grab("gru")))
+        with torch.no_grad():
+            y = model.realtime_process(mix_t[..., :L])
+            feats = None
+            if isinstance(y, tuple):
+                y, feats = y
+            vout[f"{tag}_out"] = t2n(y)
+            for h in hooks:
+                h.remove()
+            for k, v in stages.items():
+                vout[f"{tag}_stage_{k}"] = np.stack(v[1:3])
+            if feats is not None and "tiny" in tag:  # student features: [N*B, C, F, T] per tap (distillation_crn.py:467-471)
+                for i, f in enumerate(feats):
+                    vout[f"{tag}_feat{i}"] = t2n(f)[2:6]
+            if cont:
+                y2 = model.realtime_process(mix_t[..., L:], True)
+                vout[f"{tag}_cont_out"] = t2n(y2[0] if isinstance(y2, tuple) else y2)
+    with open(os.path.join(HERE, "crn_variant_keys.json"), "w") as f:
+        json.dump(vkeys, f, indent=0)
+    np.savez_compressed(os.path.join(HERE, "crn_variants_golden.npz"), **vout)
+    print("wrote crn_variants_golden.npz", os.path.getsize(os.path.join(HERE, "crn_variants_golden.npz")), "bytes;", len(vout), "arrays")
 
     np.savez_compressed(os.path.join(HERE, "crn_golden.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "crn_golden.npz"))

@@ -103,3 +103,41 @@ def test_full_b1_ragged(golden):
     mix, _ = synth.synth_utterances(1, 5000, 3, seed=11)
     y = o.realtime_process(mix)
     assert rel_rms(y, golden["full400_b1_L5000_out"]) < 5e-5
+
+
+# ---- a12 / a13: CRN_ELU.py and the distilled-student architecture (distillation_crn.py) -----------------------
+from conftest import STUDENT400, spec_of_variant  # noqa: E402
+
+
+def _mkv(cfg, variant):
+    o = orc.CrnOracle(**cfg, variant=variant)
+    o.load_state_dict(synth.make_state_dict(spec_of_variant(cfg, variant), seed=0))
+    return o
+
+
+@pytest.mark.parametrize("tag,variant", [("elu_tiny", 1), ("student_tiny", 2)])
+def test_variant_tiny_end_to_end_and_stages(vgolden, tag, variant):
+    o = _mkv(TINY, variant)
+    mix, _ = synth.synth_utterances(2, 8000 + 4800, 3, seed=7)
+    y = o.realtime_process(mix[..., :8000])
+    assert rel_rms(y, vgolden[f"{tag}_out"]) < 2e-5
+    y2 = o.realtime_process(mix[..., 8000:], flag=True)
+    assert rel_rms(y2, vgolden[f"{tag}_cont_out"]) < 2e-5
+    seg, gap = orc.segmentation(np.concatenate([np.zeros((2, 3, 1600), np.float32), mix[..., :8000]], -1), 3200)
+    N = seg.shape[0] // 2
+    sp = o.stft(seg.reshape(-1, 3200)).reshape(2, N, 3, 201, 21, 2)
+    o.reset(2)
+    for n in range(3):
+        o.forward(sp[:, n])
+        if n == 0:
+            continue
+        for k in ("enc0", "enc1", "enc2", "enc3", "gru", "dec0", "dec1", "dec2", "dec3"):
+            ref = vgolden[f"{tag}_stage_{k}"][n - 1]
+            assert rel_rms(o.tap(k).reshape(ref.shape), ref) < 2e-5, (k, n)
+
+
+@pytest.mark.parametrize("tag,cfg,variant", [("elu_full400", FULL400, 1), ("student_full400", STUDENT400, 2)])
+def test_variant_full_end_to_end(vgolden, tag, cfg, variant):
+    o = _mkv(cfg, variant)
+    mix, _ = synth.synth_utterances(2, 6400, 3, seed=7)
+    assert rel_rms(o.realtime_process(mix), vgolden[f"{tag}_out"]) < 5e-5
