@@ -49,6 +49,10 @@ typedef struct {
     int32_t kernel_size;                /* 3 */
     int32_t n_fft, win, hop;
     int32_t segment_length;             /* K = 3200 */
+    int32_t variant;                    /* 0 = CRN.py TemporalCRN (ReLU); 1 = CRN_ELU.py TemporalCRN (ELU, gated 1x1 convs,
+                                           three 5x5 frequency-dilated preconv blocks, atan2 phase; CRN_ELU.py:321-365);
+                                           2 = distillation_crn.py TemporalCRN, the student architecture (as 1, but arctan
+                                           phase and gLN denominator sqrt(var)+eps; distillation_crn.py:51,340) */
 } se_config;
 
 typedef struct se_engine se_engine;
@@ -85,11 +89,13 @@ int se_istft(se_engine *e, const float *spec, int n, float *wav, void *stream);
 int se_forward(se_engine *e, const float *x, float *y, void *stream);
 
 /* Debug taps of the last forward, converted to the reference's [B, C, F, T] layout, copied to HOST.
- * name: "feat", "enc0".."encN", "gru", "dec0".."decN".  Synchronises the stream.  *count = elements. */
+ * name: "feat" (encoder input, after the preconv blocks for variants 1/2), "enc0".."encN", "gru", "dec0".."decN".
+ * Synchronises the stream.  *count = elements. */
 int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
 
 /* Streaming state hand-over: encoder time buffers "buf<i>" [B, Cin, F, 2d] and GRU
- * hidden "h" [layers, B, H] in the reference's layouts, HOST pointers.  Synchronises. */
+ * hidden "h" [layers, B, H] in the reference's layouts, HOST pointers; variants 1/2 add the preconv buffers
+ * "pbuf<i>" [B, 2M-1, F, 4].  Synchronises. */
 int se_export_state(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
 int se_import_state(se_engine *e, const char *name, const float *host_in, int64_t count, void *stream);
 

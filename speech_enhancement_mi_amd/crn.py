@@ -31,10 +31,13 @@ class _Norm(nn.Module):  # GlobalLayerNorm parameter holder, CRN.py:120-132
         self.bias = nn.Parameter(torch.zeros(shape))
 
 
-class _Conv(nn.Module):  # TemporalConv2d parameter holder, CRN.py:300-319
-    def __init__(self, cin, cout, ks, dil, dropout):
+class _Conv(nn.Module):  # TemporalConv2d parameter holder, CRN.py:300-319; CRN_ELU.py:222-230 adds the gated 1x1 pair
+    def __init__(self, cin, cout, kernel, stride, dil, dropout, gated=False):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, (5, ks), stride=(2, 1), padding=(2, 0), dilation=(1, dil))
+        self.conv = nn.Conv2d(cin, cout, kernel, stride=stride, padding=(2 * dil[0], 0), dilation=dil)
+        if gated:  # registration order matters: it is the reference's state_dict order
+            self.conv_trans = nn.Conv2d(cout, cout, 1, stride=1, padding=0)
+            self.conv_gated = nn.Conv2d(cout, cout, 1, stride=1, padding=0)
         self.dropout = nn.Dropout(dropout)
         self.net = nn.Sequential(self.conv, self.dropout)
         self.norm = _Norm(cout)
@@ -61,6 +64,8 @@ class _Seq(nn.Module):  # SequenceModel parameter holder, CRN.py:196-254
 
 
 class TemporalCRN(nn.Module):
+    _VARIANT = 0  # 0 = CRN.py; subclasses: 1 = CRN_ELU.py (crn_elu.TemporalCRN), 2 = distillation_crn.py student
+
     def __init__(self, num_channels, num_freqs, hidden, segment_length, num_layers=1, num_inputs=3, kernel_size=3,
                  dropout=0.0, sample_rate=16000, win_length=25, hop_length=10, n_fft=400):
         super().__init__()
@@ -70,13 +75,17 @@ class TemporalCRN(nn.Module):
         self.num_freqs = num_freqs
         self._cfg_args = dict(num_channels=list(num_channels), num_freqs=num_freqs, hidden=hidden, segment_length=segment_length,
                               num_layers=num_layers, num_inputs=num_inputs, kernel_size=kernel_size, sample_rate=sample_rate,
-                              win_length=win_length, hop_length=hop_length, n_fft=n_fft)
+                              win_length=win_length, hop_length=hop_length, n_fft=n_fft, variant=self._VARIANT)
         L = len(num_channels)
+        gated = self._VARIANT != 0
+        if gated:  # CRN_ELU.py:335-340: three 5x5 blocks with frequency dilation 1, 2, 4
+            c0 = 2 * num_inputs - 1
+            self.preconvlist = nn.ModuleList([_Conv(c0, c0, (5, 5), (1, 1), (fd, 1), dropout, gated=True) for fd in (1, 2, 4)])
         convs, deconvs = [], []
         for i in range(L):  # CRN.py:431-444
             cin = (2 * num_inputs - 1) if i == 0 else num_channels[i - 1]
             cout = num_channels[i]
-            convs.append(_Conv(cin, cout, kernel_size, 2 ** i, dropout))
+            convs.append(_Conv(cin, cout, (5, kernel_size), (2, 1), (1, 2 ** i), dropout, gated=gated))
             d = 2 ** (L - i - 1)
             deconvs.insert(0, _Deconv(cout, 2 if i == 0 else cin, kernel_size, d, dropout))
         self.convlist = nn.ModuleList(convs)

@@ -25,7 +25,7 @@ namespace se {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxTaps = 15;
+constexpr int kMaxTaps = 25;  // 5x5 frequency-dilated preconv blocks of CRN_ELU.py:335-340
 
 struct ConvArgs {
     const float *x;      // [B][Ci][T][Fi] current step
@@ -44,7 +44,12 @@ struct ConvArgs {
     int rowgrp[kMaxTaps];  // row group (time tap index) of each tap
     int coloff[kMaxTaps];
     int CC, nchunk, tiles_per_wg, St;
-    int relu_lo, relu_hi;  // output channels in [relu_lo, relu_hi) get ReLU
+    int relu_lo, relu_hi;  // GEMM rows in [relu_lo, relu_hi) get the activation `act`
+    int act;               // 1 = ReLU (CRN.py), 2 = ELU (CRN_ELU.py:226,280)
+    // gate_pairs: GEMM rows (2c, 2c+1) hold conv_trans_c and conv_gated_c of the gated 1x1 pair
+    // (CRN_ELU.py:240: out = conv_trans(out) * sigmoid(conv_gated(out))); the epilogue writes channel c = trans * sigmoid(gated)
+    int gate_pairs;
+    int Cy, cy0;           // channels of y per stream and channel offset of this launch (row -> channel cy0 + row[/2])
     // per-workgroup partial (sum, sum of squares) of the stored activations of channels [stats_lo, stats_hi),
     // written to stats[(b*stats_nslot + stats_slot0 + blockIdx.x)*2 + {0,1}] for the global layer norm that
     // follows every block (CRN.py:135-149); nullptr = off.  One slot per workgroup -> deterministic.
@@ -65,6 +70,50 @@ __device__ __forceinline__ void conv_stats_store(const ConvArgs &a, float s, flo
         o[0] = (red[0] + red[2]) + (red[4] + red[6]);
         o[1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
+}
+
+__device__ __forceinline__ float conv_act(float v, int act) {
+    return act == 1 ? fmaxf(v, 0.0f) : (act == 2 ? (v > 0.0f ? v : expf(v) - 1.0f) : v);
+}
+
+// Epilogue shared by k_conv_igemm and k_conv_x6 (both leave 32x32 accumulator tiles: column = position on the lane,
+// rows = GEMM rows in the 16 registers): bias, activation, optional gated-pair product, store [B][Cy][T][Fy], and the
+// per-workgroup partial (sum, sum of squares) for the global layer norm that follows.
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[NT], const bool (&lane_ok)[NT],
+                                              const int (&pos_t)[NT], const int (&pos_m)[NT], int mt, int half, float *scratch, int b) {
+    const long ys_c = (long)a.T * a.Fy;
+    float *yb = a.y + ((long)b * a.Cy + a.cy0) * ys_c;
+    float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        if (!lane_ok[i]) continue;
+        float *yp = yb + (long)pos_t[i] * a.Fy + a.os * pos_m[i] + a.oo;
+        if (a.gate_pairs) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // even
+                if (row + 1 < a.Co) {
+                    const float tr = acc[i][r] + a.bias[row], gt = acc[i][r + 1] + a.bias[row + 1];
+                    const float v = tr * (1.0f / (1.0f + expf(-gt)));
+                    yp[(row >> 1) * ys_c] = v;
+                    ssum += v; ssq += v * v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < a.Co) {
+                    float v = acc[i][r] + a.bias[co];
+                    if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
+                    yp[co * ys_c] = v;
+                    if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
+                }
+            }
+        }
+    }
+    if (a.stats) conv_stats_store(a, ssum, ssq, scratch, b);
 }
 
 constexpr int kPatchPerThread = 16;   // patch elements staged per thread per chunk  (chunk patch <= 4096 floats)
@@ -235,41 +284,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {
         }
     }
     __syncthreads();
-    // ---- epilogue: bias, ReLU, store [B][Co][T][Fy], partial norm statistics ----
-    const long ys_c = (long)a.T * a.Fy;
-    float *yb = a.y + (long)b * a.Co * ys_c;
-    float ssum = 0.0f, ssq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NT; i++) {
-        if (!lane_ok[i]) continue;
-        float *yp = yb + (long)pos_t[i] * a.Fy + a.os * pos_m[i] + a.oo;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < a.Co) {
-                float v = acc[i][r] + a.bias[co];
-                if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
-                yp[co * ys_c] = v;
-                if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
-            }
-        }
-    }
-    if (a.stats) conv_stats_store(a, ssum, ssq, lds, b);  // lds is free again: all waves are past the MFMA loop
+    conv_epilogue<NT>(a, acc, lane_ok, pos_t, pos_m, mt, half, lds, b);  // lds is free again: all waves are past the MFMA loop
 }
 
-// Convolutions with <= 4 output channels (the last decoder block, 16 -> 2 channels: a 32-row MFMA tile would be
-// 94 % padding) run on the vector ALU, one thread per output position, reading the input straight from
-// L2/HBM: consecutive lanes read consecutive frequencies (coalesced) and all NTAP x Cin loads of a thread are
-// independent, so the memory system stays full; an LDS patch (as in k_conv_igemm) would re-stage a 3-time-tap
-// halo that is 8x larger than the two output rows a workgroup produces.  Weights [tap][ci][4] sit in LDS and
-// are read as broadcast float4.
-template <int NTAP>
+// Convolutions with <= 8 output channels (the last decoder block, 16 -> 2 channels, and the 5 -> 5 channel 5x5
+// preconv blocks of CRN_ELU: a 32-row MFMA tile would be 84-94 % padding) run on the vector ALU, one thread per
+// output position, reading the input straight from L2/HBM: consecutive lanes read consecutive frequencies
+// (coalesced) and all NTAP loads of a channel are independent, so the memory system stays full; an LDS patch (as in
+// k_conv_igemm) would re-stage a time-tap halo several times larger than the rows a workgroup produces.
+// Weights [tap][ci][4*W4] sit in LDS and are read as broadcast float4.
+template <int NTAP, int W4>
 __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int P = a.T * a.FP;
-    const int nw = NTAP * a.Ci * 4;  // host lays the weights out as ONE chunk: [NTAP][Ci][4]
+    constexpr int CW = 4 * W4;
+    const int nw = NTAP * a.Ci * CW;  // host lays the weights out as ONE chunk: [NTAP][Ci][CW]
     for (int i = tid; i < nw; i += 256) lds[i] = a.w[i];
     __syncthreads();
     const int p = blockIdx.x * 256 + tid;
@@ -280,37 +311,42 @@ __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     const float *xb = a.x + (long)b * a.Ci * xs_c;
     const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : xb;
     const float *src[NTAP];
-    bool ok[NTAP];
+    unsigned okbits = 0;
 #pragma unroll
     for (int k = 0; k < NTAP; k++) {
         const int ts = t + a.tlo_off + a.rowgrp[k] * a.dil;
         const int fi = a.s * m + a.coloff[k] - a.colpad;
         const bool hist = ts < 0;
-        ok[k] = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
+        const bool ok = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
+        okbits |= (ok ? 1u : 0u) << k;
         const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1), fic = min(max(fi, 0), a.Fi - 1);
         src[k] = (hist ? xpb : xb) + (long)tsc * a.Fi + fic;
     }
-    float4 acc = make_float4(0, 0, 0, 0);
+    float acc[CW];
+#pragma unroll
+    for (int j = 0; j < CW; j++) acc[j] = 0.0f;
     for (int c = 0; c < a.Ci; c++) {
         float v[NTAP];
 #pragma unroll
         for (int k = 0; k < NTAP; k++) v[k] = src[k][c * xs_c];
 #pragma unroll
         for (int k = 0; k < NTAP; k++) {
-            const float x = ok[k] ? v[k] : 0.0f;
-            const float4 w = *reinterpret_cast<const float4 *>(lds + (k * a.Ci + c) * 4);
-            acc.x += w.x * x; acc.y += w.y * x; acc.z += w.z * x; acc.w += w.w * x;
+            const float x = ((okbits >> k) & 1u) ? v[k] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < W4; q++) {
+                const float4 w = *reinterpret_cast<const float4 *>(lds + (k * a.Ci + c) * CW + 4 * q);
+                acc[4 * q] += w.x * x; acc[4 * q + 1] += w.y * x; acc[4 * q + 2] += w.z * x; acc[4 * q + 3] += w.w * x;
+            }
         }
     }
     const long ys_c = (long)a.T * a.Fy;
-    float *yp = a.y + (long)b * a.Co * ys_c + (long)t * a.Fy + a.os * m + a.oo;
-    const float r4[4] = {acc.x, acc.y, acc.z, acc.w};
+    float *yp = a.y + ((long)b * a.Cy + a.cy0) * ys_c + (long)t * a.Fy + a.os * m + a.oo;
     float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
-    for (int co = 0; co < 4; co++)
+    for (int co = 0; co < CW; co++)
         if (co < a.Co && live) {
-            float v = r4[co] + a.bias[co];
-            if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
+            float v = acc[co] + a.bias[co];
+            if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
             yp[co * ys_c] = v;
             if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
         }

@@ -164,26 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
         }
     }
     __syncthreads();
-    // ---- epilogue: bias, ReLU, store [B][Co][T][Fy], partial norm statistics (identical to k_conv_igemm) ----
-    const long ys_c = (long)a.T * a.Fy;
-    float *yb = a.y + (long)b * a.Co * ys_c;
-    float ssum = 0.0f, ssq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NT; i++) {
-        if (!lane_ok[i]) continue;
-        float *yp = yb + (long)pos_t[i] * a.Fy + a.os * pos_m[i] + a.oo;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < a.Co) {
-                float v = acc[i][r] + a.bias[co];
-                if (co >= a.relu_lo && co < a.relu_hi) v = fmaxf(v, 0.0f);
-                yp[co * ys_c] = v;
-                if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
-            }
-        }
-    }
-    if (a.stats) conv_stats_store(a, ssum, ssq, reinterpret_cast<float *>(planes), b);
+    conv_epilogue<NT>(a, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b);
 }
 
 }  // namespace se

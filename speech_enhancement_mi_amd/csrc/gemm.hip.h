@@ -21,7 +21,7 @@ struct GemmArgs {
     float *C;
     int M, N, K;
     long lda, ldw, ldc;
-    int relu;
+    int relu;  // activation: 0 none, 1 ReLU, 2 ELU (CRN_ELU.py:365)
 };
 
 // Stage 128 rows x 32 k of a K-contiguous operand into LDS (row stride kGemmLd).  Loads are unconditional
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(GemmArgs a) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < a.M) {
                     float v = acc[i][j][r] + bs;
-                    if (a.relu) v = fmaxf(v, 0.0f);
+                    v = conv_act(v, a.relu);
                     a.C[(long)m * a.ldc + n] = v;
                 }
             }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < a.M) {
                     float v = acc[i][j][r] + bs;
-                    if (a.relu) v = fmaxf(v, 0.0f);
+                    v = conv_act(v, a.relu);
                     a.C[(long)m * a.ldc + n] = v;
                 }
             }

@@ -19,6 +19,11 @@ namespace se {
 
 constexpr float kEps = 1e-8f;  // CRN.py:11
 
+// gLN denominator: sqrt(var + eps) + eps (CRN.py:149, CRN_ELU.py:51) or sqrt(var) + eps (distillation_crn.py:51)
+__device__ __forceinline__ float gln_inv(float var, int eps_outside_only) {
+    return 1.0f / ((eps_outside_only ? sqrtf(var) : sqrtf(var + kEps)) + kEps);
+}
+
 __device__ inline double block_sum(double v, double *red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -32,7 +37,7 @@ __device__ inline double block_sum(double v, double *red) {
 }
 
 // mean and 1/(sqrt(var+eps)+eps) of n contiguous floats (two-pass, biased variance)
-__device__ inline void stream_stats(const float *x, long n, double *red, float &mean, float &inv) {
+__device__ inline void stream_stats(const float *x, long n, double *red, float &mean, float &inv, int eps_mode = 0) {
     float part = 0.0f;
     for (long i = threadIdx.x; i < n; i += blockDim.x) part += x[i];
     const double s = block_sum((double)part, red);
@@ -44,7 +49,7 @@ __device__ inline void stream_stats(const float *x, long n, double *red, float &
     }
     const double q = block_sum((double)p2, red);
     const float var = (float)(q / (double)n);
-    inv = 1.0f / (sqrtf(var + kEps) + kEps);
+    inv = gln_inv(var, eps_mode);
 }
 
 // ---- featurise: spec (b, m, t, f) -> feat [B][2M-1][T][F] --------------------------------------
@@ -53,6 +58,7 @@ struct FeatArgs {
     long sB, sM, sT, sF;  // strides in cf2 units
     float *feat;
     int M, T, F;
+    int atan2_phase;  // 0: arctan(im/(re+eps)+eps) (CRN.py:464, distillation_crn.py:340); 1: atan2(im, re) (CRN_ELU.py:370)
 };
 
 __global__ void k_featurize(FeatArgs a) {
@@ -67,7 +73,7 @@ __global__ void k_featurize(FeatArgs a) {
     for (int m = 0; m < a.M; m++) {
         const cf2 v = s[(long)m * a.sM];
         o[(long)m * TF] = sqrtf(v.x * v.x + v.y * v.y + 1e-10f);
-        const float ang = atanf(v.y / (v.x + kEps) + kEps);  // arctan, not atan2 (CRN.py:464)
+        const float ang = a.atan2_phase ? atan2f(v.y, v.x) : atanf(v.y / (v.x + kEps) + kEps);
         if (m == 0) ang0 = ang;
         else o[(long)(a.M + m - 1) * TF] = ang0 - ang;
     }
@@ -82,6 +88,7 @@ struct GlnArgs {
     int mode;  // 0: [C][T][F] -> same, affine per C | 1: [C][T][F] -> [T][C*F], affine per C
                // 2: [T][D=C*F] -> [C][T][F], affine per D (GlobalLayerNorm(last=True), CRN.py:127-129)
     int C, T, F;
+    int eps_mode;
 };
 
 __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
     const float *x = a.x + (long)blockIdx.x * a.n;
     float *y = a.y + (long)blockIdx.x * a.n;
     float mean, inv;
-    stream_stats(x, a.n, red, mean, inv);
+    stream_stats(x, a.n, red, mean, inv, a.eps_mode);
     const int TF = a.T * a.F, F = a.F, T = a.T, C = a.C;
     if (a.mode == 0) {
         for (long i = threadIdx.x; i < a.n; i += blockDim.x) {
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(1024) void k_final_mask(MaskArgs a) {
 
 // ---- elementwise variants: statistics come from the producing convolution's per-workgroup partials ----------
 // (one pass over the tensor instead of three, full-chip grid instead of one workgroup per stream)
-struct SlabStats { const float *slab; int nslot; long n; };  // slab [B][nslot][2] = (sum, sum of squares)
+struct SlabStats { const float *slab; int nslot; long n; int eps_mode; };  // slab [B][nslot][2] = (sum, sum of squares)
 
 __device__ __forceinline__ void slab_mean_inv(const SlabStats &st, int b, float *sm /*[2] shared*/, float &mean, float &inv) {
     if (threadIdx.x < 64) {
@@ -190,7 +197,7 @@ __device__ __forceinline__ void slab_mean_inv(const SlabStats &st, int b, float 
             double var = q / (double)st.n - m * m;
             if (var < 0) var = 0;
             sm[0] = (float)m;
-            sm[1] = 1.0f / (sqrtf((float)var + kEps) + kEps);
+            sm[1] = gln_inv((float)var, st.eps_mode);
         }
     }
     __syncthreads();
@@ -205,8 +212,12 @@ struct GlnEwArgs {
     SlabStats st;
     int mode;  // 0: [C][T][F] -> same | 1: [C][T][F] -> [T][C*F]
     int C, T, F;
+    const float *res;  // mode 0 only: y = gLN(x) + res (the `m(x) + x` of the preconv blocks, CRN_ELU.py:375-376)
 };
 
+// VW = 4: float4 path (n % 4 == 0, so every stream's base stays 16-B aligned); VW = 1: scalar path for odd sizes
+// (the 5-channel preconv tensors of CRN_ELU: 5*21*201 elements).
+template <int VW>
 __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     __shared__ float sm[2];
     const int b = blockIdx.y;
@@ -215,25 +226,38 @@ __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     const long n = a.st.n;
     const float *x = a.x + (long)b * n;
     float *y = a.y + (long)b * n;
+    const float *res = a.res ? a.res + (long)b * n : nullptr;
     const int TF = a.T * a.F, F = a.F, C = a.C;
     const float invTF = 1.0f / (float)TF;
-    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(x + i);  // n % 4 == 0 (host-checked)
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
-        int cc[4];
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VW; i < n; i += (long)gridDim.x * blockDim.x * VW) {
+        float vv[VW], o[VW];
+        int cc[VW];
+        if (VW == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + i);
+            vv[0] = v.x; vv[VW > 1 ? 1 : 0] = v.y; vv[VW > 2 ? 2 : 0] = v.z; vv[VW > 3 ? 3 : 0] = v.w;
+        } else {
+            vv[0] = x[i];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < VW; k++) {
             int c = (int)(((float)(i + k) + 0.5f) * invTF);  // (i+k) / TF, exact for n < 2^22
             c = min(c, C - 1);
             cc[k] = c;
             o[k] = (vv[k] - mean) * inv * a.w[c] + a.b[c];
         }
         if (a.mode == 0) {
-            *reinterpret_cast<float4 *>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+            if (VW == 4) {
+                if (res) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(res + i);
+                    o[0] += r4.x; o[VW > 1 ? 1 : 0] += r4.y; o[VW > 2 ? 2 : 0] += r4.z; o[VW > 3 ? 3 : 0] += r4.w;
+                }
+                *reinterpret_cast<float4 *>(y + i) = make_float4(o[0], o[VW > 1 ? 1 : 0], o[VW > 2 ? 2 : 0], o[VW > 3 ? 3 : 0]);
+            } else {
+                y[i] = o[0] + (res ? res[i] : 0.0f);
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < VW; k++) {
                 const int r = (int)(i + k) - cc[k] * TF, t = r / F, f = r - t * F;
                 y[((long)t * C + cc[k]) * F + f] = o[k];
             }

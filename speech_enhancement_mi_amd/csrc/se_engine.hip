@@ -56,7 +56,9 @@ struct ConvPlan {
 struct Level {  // one encoder/decoder level
     ConvPlan enc;
     ConvPlan dec_even, dec_odd, skip;
-    DevBuf enc_nw, enc_nb, dec_nw, dec_nb, dec_mnw, dec_mnb;
+    ConvPlan gate[2];      // CRN_ELU encoder: conv_trans/conv_gated 1x1 pair, <= 64 output channels per launch
+    ConvPlan pre, pre_gate; // CRN_ELU preconv block i (levels 0..2): 5x5 frequency-dilated conv + its gated pair
+    DevBuf enc_nw, enc_nb, dec_nw, dec_nb, dec_mnw, dec_mnb, pre_nw, pre_nb;
 };
 
 }  // namespace
@@ -83,6 +85,7 @@ struct se_engine {
     DevBuf wih[4], whh[4], bih[4], bhh[4], fcw, fcb, gnw, gnb;
     DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
+    int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
     int conv_mode = 6;        // SE_CONV_MODE: 0 = fp32 MFMA (k_conv_igemm), 6 = bf16x6 where Cin % 8 == 0 (default)
 
     // state + activations for B streams
@@ -95,6 +98,8 @@ struct se_engine {
     int hcur[4]{};
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
     DevBuf enc_stats[SE_MAX_LEVELS], dec_stats[SE_MAX_LEVELS], skip_stats[SE_MAX_LEVELS];  // [B][slots][2] norm partials
+    DevBuf enc_g[SE_MAX_LEVELS];           // CRN_ELU: gated encoder output before the norm
+    DevBuf pin[3][2], pre_raw, pre_g, pre_stats[3];  // CRN_ELU preconv chain (inputs ping-ponged: they carry 4 history columns)
     DevBuf yseg, scratch;
 
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -232,27 +237,31 @@ const std::vector<float> *param(se_engine *e, const std::string &key, size_t exp
 template <class WSel>
 int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy, int s, int os, int oo, int colpad,
               int tlo_off, int ngroup, int dil, int St, const std::vector<std::array<int, 4>> &taps /*kf,kt,rowgrp,coloff*/,
-              WSel wsel, const std::vector<float> &bias, int relu_lo, int relu_hi) {
+              WSel wsel, const std::vector<float> &bias, int relu_lo, int relu_hi, int act = 1, int gate_pairs = 0, int Cy = -1,
+              int cy0 = 0) {
+    if (Cy < 0) Cy = Co;
+    pl.x6 = false;
     pl.active = FP > 0;
     if (!pl.active) return 0;
     const int T = e->T;
     const int ntap = (int)taps.size();
     const int P = T * FP, tiles = (P + 31) / 32;
-    if (Co <= 4) {  // vector-ALU variant: one thread per position, direct global reads, weights [tap][ci][4] in LDS
+    if (Co <= 8 && !gate_pairs) {  // vector-ALU variant: one thread per position, direct global reads, weights [tap][ci][CW] in LDS
+        const int CW = Co <= 4 ? 4 : 8;
         ConvArgs &a = pl.a;
-        a.Ci = Ci; a.Co = Co; a.CoPad = 4; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
+        a.Ci = Ci; a.Co = Co; a.CoPad = CW; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
         a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = 0;
         a.ntap = ntap; a.CC = Ci; a.nchunk = 1; a.tiles_per_wg = 8; a.St = St;
-        a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+        a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = 0; a.Cy = Cy; a.cy0 = cy0;
         for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
         pl.NT = 0;  // marks the small kernel
         pl.grid_x = (P + 255) / 256;
-        pl.lds = sizeof(float) * (size_t)ntap * Ci * 4;
+        pl.lds = sizeof(float) * (size_t)ntap * Ci * CW;
         if (pl.lds > 64 * 1024) return fail(e, SE_ERR_ARG, "small-conv weights do not fit LDS");
-        std::vector<float> w((size_t)ntap * Ci * 4, 0.0f);
+        std::vector<float> w((size_t)ntap * Ci * CW, 0.0f);
         for (int t = 0; t < ntap; t++)
             for (int ci = 0; ci < Ci; ci++)
-                for (int co = 0; co < Co; co++) w[((size_t)t * Ci + ci) * 4 + co] = wsel(ci, co, taps[t][0], taps[t][1]);
+                for (int co = 0; co < Co; co++) w[((size_t)t * Ci + ci) * CW + co] = wsel(ci, co, taps[t][0], taps[t][1]);
         int rc = dev_upload(e, pl.w, w);
         if (rc) return rc;
         return dev_upload(e, pl.bias, bias);
@@ -281,7 +290,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
             a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
             a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
             a.ntap = ntap; a.CC = 8; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
-            a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+            a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = gate_pairs; a.Cy = Cy; a.cy0 = cy0;
             for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
             pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true;
             pl.lds = std::max<size_t>((size_t)3 * Rmax * St * 16, 64);
@@ -333,7 +342,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
     a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
     a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
-    a.relu_lo = relu_lo; a.relu_hi = relu_hi;
+    a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = gate_pairs; a.Cy = Cy; a.cy0 = cy0;
     for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
     pl.NT = NT;
     pl.grid_x = n_wg;
@@ -369,9 +378,30 @@ int prepare_weights(se_engine *e) {
         const float *wp = w->data();
         int rc = plan_conv(e, e->lv[i].enc, Ci, Co, Fo, Fi, Fo, 2, 1, 0, 2, -2 * d, 3, d, Fi + 4, taps,
                            [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; },
-                           *b, 0, Co);
+                           *b, 0, Co, e->act);
         if (rc) return rc;
         e->lv[i].enc.flops = 2.0 * Co * Ci * 15 * Fo * e->T;
+        e->lv[i].gate[0].active = e->lv[i].gate[1].active = false;
+        if (e->variant) {  // conv_trans / conv_gated 1x1 pair (CRN_ELU.py:223-224,240), <= 64 output channels per launch
+            auto *tw = param(e, p + "conv_trans.weight", (size_t)Co * Co);
+            auto *tb = param(e, p + "conv_trans.bias", Co);
+            auto *gw = param(e, p + "conv_gated.weight", (size_t)Co * Co);
+            auto *gb = param(e, p + "conv_gated.bias", Co);
+            if (!tw || !tb || !gw || !gb) return SE_ERR_PARAM_MISSING;
+            const float *twp = tw->data(), *gwp = gw->data();
+            const int nparts = Co > 64 ? 2 : 1, cpart = (Co + nparts - 1) / nparts;
+            std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
+            for (int part = 0; part < nparts; part++) {
+                const int c0 = part * cpart, cn = std::min(cpart, Co - c0);
+                std::vector<float> bias2(2 * cn);
+                for (int c = 0; c < cn; c++) { bias2[2 * c] = (*tb)[c0 + c]; bias2[2 * c + 1] = (*gb)[c0 + c]; }
+                rc = plan_conv(e, e->lv[i].gate[part], Co, 2 * cn, Fo, Fo, Fo, 1, 1, 0, 0, 0, 1, 0, Fo, t1,
+                               [=](int ci, int row, int, int) { const int c = c0 + row / 2; return (row & 1) ? gwp[(size_t)c * Co + ci] : twp[(size_t)c * Co + ci]; },
+                               bias2, 0, 0, 0, /*gate_pairs=*/1, /*Cy=*/Co, /*cy0=*/c0);
+                if (rc) return rc;
+                e->lv[i].gate[part].flops = 2.0 * 2 * cn * Co * Fo * e->T;
+            }
+        }
         if ((rc = dev_upload(e, e->lv[i].enc_nw, *nw))) return rc;
         if ((rc = dev_upload(e, e->lv[i].enc_nb, *nb))) return rc;
     }
@@ -391,9 +421,9 @@ int prepare_weights(se_engine *e) {
             for (int kt = 0; kt < 3; kt++) te.push_back({kf, kt, 2 - kt, 2 - kf / 2});
         for (int kf = 1; kf < 5; kf += 2)
             for (int kt = 0; kt < 3; kt++) to.push_back({kf, kt, 2 - kt, 1 + (3 - kf) / 2});
-        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, te, wsel, *b, 0, Co);
+        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, te, wsel, *b, 0, Co, e->act);
         if (rc) return rc;
-        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 3, d, Fi + 2, to, wsel, *b, 0, Co);
+        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 3, d, Fi + 2, to, wsel, *b, 0, Co, e->act);
         if (rc) return rc;
         // SURVEY 8d counts a transposed conv as Cin*Cout*15*Fi*T MACs; split 9:6 over the two parity launches
         e->lv[j].dec_even.flops = 2.0 * Ci * Co * 9 * Fi * e->T;
@@ -415,12 +445,43 @@ int prepare_weights(se_engine *e) {
             const int Fr = e->F[lvl];
             rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
                            [=](int ci, int co, int, int) { return co < Co ? mwp[(size_t)co * Co + ci] : rwp[(size_t)(co - Co) * Co + ci]; },
-                           bias2, Co, 2 * Co);
+                           bias2, Co, 2 * Co, e->act);
             if (rc) return rc;
             e->lv[j].skip.flops = 2.0 * 2 * Co * Co * Fr * e->T;
             if ((rc = dev_upload(e, e->lv[j].dec_mnw, *mnw))) return rc;
             if ((rc = dev_upload(e, e->lv[j].dec_mnb, *mnb))) return rc;
         }
+    }
+    for (int i = 0; i < e->npre; i++) {  // CRN_ELU.py:335-340: Conv2d(5x5, dilation (fd,1), padding (2fd,4)) + gated pair + gLN
+        const int C0 = e->Ch[0], F0 = e->F[0], fd = 1 << i;
+        const std::string p = "preconvlist." + std::to_string(i) + ".";
+        auto *w = param(e, p + "conv.weight", (size_t)C0 * C0 * 25);
+        auto *b = param(e, p + "conv.bias", C0);
+        auto *tw = param(e, p + "conv_trans.weight", (size_t)C0 * C0);
+        auto *tb = param(e, p + "conv_trans.bias", C0);
+        auto *gw = param(e, p + "conv_gated.weight", (size_t)C0 * C0);
+        auto *gb = param(e, p + "conv_gated.bias", C0);
+        auto *nw = param(e, p + "norm.weight", C0);
+        auto *nb = param(e, p + "norm.bias", C0);
+        if (!w || !b || !tw || !tb || !gw || !gb || !nw || !nb) return SE_ERR_PARAM_MISSING;
+        if (C0 > 8) return fail(e, SE_ERR_ARG, "preconv blocks support up to 8 feature channels (num_inputs <= 4)");
+        std::vector<std::array<int, 4>> taps;
+        for (int kf = 0; kf < 5; kf++)
+            for (int kt = 0; kt < 5; kt++) taps.push_back({kf, kt, kt, kf * fd});
+        const float *wp = w->data(), *twp = tw->data(), *gwp = gw->data();
+        int rc = plan_conv(e, e->lv[i].pre, C0, C0, F0, F0, F0, 1, 1, 0, 2 * fd, -4, 5, 1, F0 + 4 * fd, taps,
+                           [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * C0 + ci) * 5 + kf) * 5 + kt]; }, *b, 0, C0, 2);
+        if (rc) return rc;
+        e->lv[i].pre.flops = 2.0 * C0 * C0 * 25 * F0 * e->T;
+        std::vector<float> bias2(2 * C0);
+        for (int c = 0; c < C0; c++) { bias2[2 * c] = (*tb)[c]; bias2[2 * c + 1] = (*gb)[c]; }
+        std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
+        rc = plan_conv(e, e->lv[i].pre_gate, C0, 2 * C0, F0, F0, F0, 1, 1, 0, 0, 0, 1, 0, F0, t1,
+                       [=](int ci, int row, int, int) { const int c = row / 2; return (row & 1) ? gwp[(size_t)c * C0 + ci] : twp[(size_t)c * C0 + ci]; },
+                       bias2, 0, 0, 0, 1, C0, 0);
+        if (rc) return rc;
+        e->lv[i].pre_gate.flops = 2.0 * 2 * C0 * C0 * F0 * e->T;
+        if ((rc = dev_upload(e, e->lv[i].pre_nw, *nw)) || (rc = dev_upload(e, e->lv[i].pre_nb, *nb))) return rc;
     }
     for (int l = 0; l < e->NL; l++) {
         const std::string s = std::to_string(l);
@@ -478,9 +539,11 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
 #define SE_CONV_CASE(NTAP_, NT_) \
     case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
 #define SE_CONV_TAPS(NTAP_) SE_CONV_CASE(NTAP_, 1) SE_CONV_CASE(NTAP_, 2) SE_CONV_CASE(NTAP_, 3) SE_CONV_CASE(NTAP_, 4) \
-    case NTAP_ * 8: hipLaunchKernelGGL((k_conv_small<NTAP_>), grid, dim3(256), pl.lds, st, a); break;
+    case NTAP_ * 8: if (a.CoPad == 4) hipLaunchKernelGGL((k_conv_small<NTAP_, 1>), grid, dim3(256), pl.lds, st, a); \
+                    else hipLaunchKernelGGL((k_conv_small<NTAP_, 2>), grid, dim3(256), pl.lds, st, a); break;
     switch (a.ntap * 8 + pl.NT) {
         SE_CONV_TAPS(15) SE_CONV_TAPS(9) SE_CONV_TAPS(6) SE_CONV_TAPS(1)
+        case 25 * 8: hipLaunchKernelGGL((k_conv_small<25, 2>), grid, dim3(256), pl.lds, st, a); break;
         default: return fail(e, SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
     }
 #undef SE_CONV_TAPS
@@ -511,19 +574,23 @@ int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw
 int launch_gln(se_engine *e, const float *x, float *y, const float *w, const float *b, long n, int mode, int C, int T,
                int F, hipStream_t st) {
     ProfScope ps(e, "k_gln", "gln", 0, st);
-    GlnArgs g{x, y, w, b, n, mode, C, T, F};
+    GlnArgs g{x, y, w, b, n, mode, C, T, F, e->eps_mode};
     hipLaunchKernelGGL(k_gln, dim3(e->B), dim3(1024), 0, st, g);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
 
 int launch_gln_ew(se_engine *e, const float *x, float *y, const float *w, const float *b, const float *slab, int nslot, long n,
-                  int mode, int C, int T, int F, hipStream_t st) {
-    if (n % 4) return fail(e, SE_ERR_ARG, "tensor size %ld not a multiple of 4", n);
+                  int mode, int C, int T, int F, hipStream_t st, const float *res = nullptr) {
     ProfScope ps(e, "k_gln_ew", "gln", 0, st);
-    GlnEwArgs g{x, y, w, b, SlabStats{slab, nslot, n}, mode, C, T, F};
-    const int gx = (int)((n / 4 + 256 * 4 - 1) / (256 * 4));
-    hipLaunchKernelGGL(k_gln_ew, dim3(gx, e->B), dim3(256), 0, st, g);
+    GlnEwArgs g{x, y, w, b, SlabStats{slab, nslot, n, e->eps_mode}, mode, C, T, F, res};
+    if (n % 4 == 0) {
+        const int gx = (int)((n / 4 + 256 * 4 - 1) / (256 * 4));
+        hipLaunchKernelGGL(k_gln_ew<4>, dim3(gx, e->B), dim3(256), 0, st, g);
+    } else {
+        const int gx = (int)((n + 256 * 4 - 1) / (256 * 4));
+        hipLaunchKernelGGL(k_gln_ew<1>, dim3(gx, e->B), dim3(256), 0, st, g);
+    }
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
@@ -537,19 +604,43 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     const int cur = e->parity, prev = cur ^ 1;
     {  // features (CRN.py:463-467)
         ProfScope ps(e, "k_featurize", "featurize", 0, st);
-        FeatArgs f{spec, sB, sM, sT, sF, e->xin[0][cur].p, e->M, T, e->F[0]};
+        float *dst = e->npre ? e->pin[0][cur].p : e->xin[0][cur].p;
+        FeatArgs f{spec, sB, sM, sT, sF, dst, e->M, T, e->F[0], e->atan2_phase};
         const int TF = T * e->F[0];
         hipLaunchKernelGGL(k_featurize, dim3((TF + 255) / 256, B), dim3(256), 0, st, f);
         HIPCHECK(e, hipGetLastError());
     }
-    for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474)
+    for (int i = 0; i < e->npre; i++) {  // x = m(x) + x, three frequency-dilated blocks (CRN_ELU.py:375-376)
+        const int C0 = e->Ch[0], F0 = e->F[0];
+        const long n = (long)C0 * T * F0;
+        if ((rc = launch_conv(e, e->lv[i].pre, e->pin[i][cur].p, e->pin[i][prev].p, e->pre_raw.p, st, ("pre" + std::to_string(i)).c_str()))) return rc;
+        const int ns = e->lv[i].pre_gate.grid_x;
+        if ((rc = launch_conv(e, e->lv[i].pre_gate, e->pre_raw.p, nullptr, e->pre_g.p, st, ("pre_gate" + std::to_string(i)).c_str(),
+                              e->pre_stats[i].p, ns, 0, 0, C0))) return rc;
+        float *dst = i + 1 < e->npre ? e->pin[i + 1][cur].p : e->xin[0][cur].p;
+        if ((rc = launch_gln_ew(e, e->pre_g.p, dst, e->lv[i].pre_nw.p, e->lv[i].pre_nb.p, e->pre_stats[i].p, ns, n, 0, C0, T, F0, st,
+                                e->pin[i][cur].p))) return rc;
+    }
+    for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474; CRN_ELU.py:233-247)
         const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
-        const int ns = e->lv[i].enc.grid_x;
-        if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str(),
-                              e->enc_stats[i].p, ns, 0, 0, Co))) return rc;
         const long n = (long)Co * T * Fo;
-        if (i + 1 < L) rc = launch_gln_ew(e, e->enc_raw[i].p, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 0, Co, T, Fo, st);
-        else rc = launch_gln_ew(e, e->enc_raw[i].p, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 1, Co, T, Fo, st);
+        const float *normed_src = e->enc_raw[i].p;
+        int ns = e->lv[i].enc.grid_x;
+        if (!e->variant) {
+            if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str(),
+                                  e->enc_stats[i].p, ns, 0, 0, Co))) return rc;
+        } else {
+            if ((rc = launch_conv(e, e->lv[i].enc, e->xin[i][cur].p, e->xin[i][prev].p, e->enc_raw[i].p, st, ("enc" + std::to_string(i)).c_str()))) return rc;
+            const int n0 = e->lv[i].gate[0].grid_x, n1 = e->lv[i].gate[1].active ? e->lv[i].gate[1].grid_x : 0;
+            ns = n0 + n1;
+            if ((rc = launch_conv(e, e->lv[i].gate[0], e->enc_raw[i].p, nullptr, e->enc_g[i].p, st, ("gate" + std::to_string(i)).c_str(),
+                                  e->enc_stats[i].p, ns, 0, 0, Co))) return rc;
+            if (n1 && (rc = launch_conv(e, e->lv[i].gate[1], e->enc_raw[i].p, nullptr, e->enc_g[i].p, st, ("gate" + std::to_string(i)).c_str(),
+                                        e->enc_stats[i].p, ns, n0, 0, Co))) return rc;
+            normed_src = e->enc_g[i].p;
+        }
+        if (i + 1 < L) rc = launch_gln_ew(e, normed_src, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 0, Co, T, Fo, st);
+        else rc = launch_gln_ew(e, normed_src, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 1, Co, T, Fo, st);
         if (rc) return rc;
     }
     // bottleneck (CRN.py:476-481, 256-282)
@@ -573,7 +664,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
         layer_in = seq;
         in_dim = H;
     }
-    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, 1, st, "gru_fc", e->fcw_x.p))) return rc;
+    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
     if ((rc = launch_gln(e, e->fc_out.p, e->dec_in.p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st))) return rc;
     // decoder (CRN.py:483-489)
     const float *x = e->dec_in.p;
@@ -585,7 +676,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
                               e->dec_stats[j].p, ne + no, 0, 0, Co))) return rc;
         if ((rc = launch_conv(e, e->lv[j].dec_odd, x, nullptr, e->dec_raw[j].p, st, ("dec" + std::to_string(j) + "_odd").c_str(),
                               e->dec_stats[j].p, ne + no, ne, 0, Co))) return rc;
-        const SlabStats sy{e->dec_stats[j].p, ne + no, (long)Co * T * Fo};
+        const SlabStats sy{e->dec_stats[j].p, ne + no, (long)Co * T * Fo, e->eps_mode};
         if (lvl > 0) {
             const int Fr = e->F[lvl], nk = e->lv[j].skip.grid_x;
             if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str(),
@@ -593,7 +684,7 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
             const long nu = (long)Co * T * Fr;
             if (nu % 4) return fail(e, SE_ERR_ARG, "decoder tensor size %ld not a multiple of 4", nu);
             BlendEwArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
-                           e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy, SlabStats{e->skip_stats[j].p, nk, nu}, Co, T, Fo, Fr};
+                           e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy, SlabStats{e->skip_stats[j].p, nk, nu, e->eps_mode}, Co, T, Fo, Fr};
             ProfScope ps(e, "k_dec_blend_ew", "dec_blend", 0, st);
             hipLaunchKernelGGL(k_dec_blend_ew, dim3((unsigned)((nu / 4 + 1023) / 1024), B), dim3(256), 0, st, bl);
             HIPCHECK(e, hipGetLastError());
@@ -664,6 +755,12 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     e->c = *cfg;
     e->device = device;
     e->L = L; e->M = cfg->num_inputs; e->K = cfg->segment_length; e->N = cfg->n_fft; e->H = cfg->hidden; e->NL = cfg->num_layers;
+    if (cfg->variant < 0 || cfg->variant > 2) { delete e; return fail(nullptr, SE_ERR_ARG, "variant %d unknown (0 CRN, 1 CRN_ELU, 2 student)", cfg->variant); }
+    e->variant = cfg->variant;
+    e->act = cfg->variant ? 2 : 1;
+    e->npre = cfg->variant ? 3 : 0;
+    e->atan2_phase = cfg->variant == 1;
+    e->eps_mode = cfg->variant == 2;
     e->T = 1 + cfg->segment_length / cfg->hop;
     e->F[0] = cfg->num_freqs;
     e->Ch[0] = 2 * cfg->num_inputs - 1;
@@ -704,7 +801,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
 #undef SE_CONV_ATTR
 #define SE_X6_ATTR(NTAP_)                                                                                                          \
@@ -725,7 +822,7 @@ void se_destroy(se_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
-                         &e->fcw_x, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
+                         &e->fcw_x, &e->pre_raw, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
     for (DevBuf *b : singles) dev_free(*b);
     for (int i = 0; i < 4; i++) {
         dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
@@ -737,7 +834,10 @@ void se_destroy(se_engine *e) {
         for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
         dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
-        dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]);
+        dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]); dev_free(e->enc_g[i]);
+        for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre, &l.pre_gate}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
+        dev_free(l.pre_nw); dev_free(l.pre_nb);
+        if (i < 3) { dev_free(e->pin[i][0]); dev_free(e->pin[i][1]); dev_free(e->pre_stats[i]); }
     }
     delete e;
 }
@@ -749,8 +849,13 @@ int se_load_param(se_engine *e, const char *key, const float *host_data, const i
     int idx = -1, n = 0;
     char rest[64];
     bool ok = false;
-    if (sscanf(k.c_str(), "convlist.%d.%63s", &idx, rest) == 2)
-        ok = idx >= 0 && idx < e->L && (!strcmp(rest, "conv.weight") || !strcmp(rest, "conv.bias") || !strcmp(rest, "norm.weight") || !strcmp(rest, "norm.bias"));
+    auto gated_key = [&](const char *r) {
+        return e->variant && (!strcmp(r, "conv_trans.weight") || !strcmp(r, "conv_trans.bias") || !strcmp(r, "conv_gated.weight") || !strcmp(r, "conv_gated.bias"));
+    };
+    if (sscanf(k.c_str(), "preconvlist.%d.%63s", &idx, rest) == 2)
+        ok = e->variant && idx >= 0 && idx < 3 && (!strcmp(rest, "conv.weight") || !strcmp(rest, "conv.bias") || !strcmp(rest, "norm.weight") || !strcmp(rest, "norm.bias") || gated_key(rest));
+    else if (sscanf(k.c_str(), "convlist.%d.%63s", &idx, rest) == 2)
+        ok = idx >= 0 && idx < e->L && (!strcmp(rest, "conv.weight") || !strcmp(rest, "conv.bias") || !strcmp(rest, "norm.weight") || !strcmp(rest, "norm.bias") || gated_key(rest));
     else if (sscanf(k.c_str(), "deconvlist.%d.%63s", &idx, rest) == 2) {
         static const char *names[] = {"conv.weight", "conv.bias", "norm.weight", "norm.bias", "residualmask.weight", "residualmask.bias",
                                       "residualnorm.weight", "residualnorm.bias", "residual.weight", "residual.bias"};
@@ -787,7 +892,8 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             HIPCHECK(e, hipMemsetAsync(e->xin[i][p].p, 0, nin * sizeof(float), st));
         }
         if ((rc = dev_alloc(e, e->enc_raw[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
-        if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * e->lv[i].enc.grid_x))) return rc;
+        if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * (e->lv[i].enc.grid_x + e->lv[i].gate[0].grid_x + e->lv[i].gate[1].grid_x + 1)))) return rc;
+        if (e->variant && (rc = dev_alloc(e, e->enc_g[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
         if ((rc = dev_alloc(e, e->dec_stats[i], (size_t)B * 2 * (e->lv[i].dec_even.grid_x + e->lv[i].dec_odd.grid_x + 1)))) return rc;
         if ((rc = dev_alloc(e, e->skip_stats[i], (size_t)B * 2 * (e->lv[i].skip.grid_x + 1)))) return rc;
         const int lvl = L - 1 - i;  // decoder index i
@@ -797,6 +903,15 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             if ((rc = dev_alloc(e, e->dec_uv[i], (size_t)B * 2 * Co * T * Fr))) return rc;
             if ((rc = dev_alloc(e, e->dec_out[i], (size_t)B * Co * T * Fr))) return rc;
         }
+    }
+    for (int i = 0; i < e->npre; i++) {
+        const size_t nf = (size_t)B * e->Ch[0] * T * F0;
+        for (int p = 0; p < 2; p++) {
+            if ((rc = dev_alloc(e, e->pin[i][p], nf))) return rc;
+            HIPCHECK(e, hipMemsetAsync(e->pin[i][p].p, 0, nf * sizeof(float), st));
+        }
+        if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre_gate.grid_x + 1)))) return rc;
+        if ((rc = dev_alloc(e, e->pre_raw, nf)) || (rc = dev_alloc(e, e->pre_g, nf))) return rc;
     }
     if ((rc = dev_alloc(e, e->gru_in, (size_t)B * T * D)) || (rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
         (rc = dev_alloc(e, e->seq[0], (size_t)B * T * H)) || (rc = dev_alloc(e, e->seq[1], (size_t)B * T * H)) ||
@@ -947,14 +1062,15 @@ int se_export_state(se_engine *e, const char *name, float *host_out, int64_t cap
             HIPCHECK(e, hipMemcpy(host_out + (size_t)l * B * H, e->hbuf[l][e->hcur[l]].p, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost));
         return SE_OK;
     }
-    if (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L) {
-        const int C = e->Ch[idx], F = e->F[idx], P = 2 << idx;
+    const bool is_pbuf = sscanf(name, "pbuf%d", &idx) == 1 && idx >= 0 && idx < e->npre;
+    if (is_pbuf || (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L)) {
+        const int C = is_pbuf ? e->Ch[0] : e->Ch[idx], F = is_pbuf ? e->F[0] : e->F[idx], P = is_pbuf ? 4 : (2 << idx);
         const size_t n = (size_t)B * C * F * P, nsrc = (size_t)B * C * T * F;
         if (count) *count = (int64_t)n;
         if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
         std::vector<float> h(nsrc);
         HIPCHECK(e, hipStreamSynchronize(st));
-        HIPCHECK(e, hipMemcpy(h.data(), e->xin[idx][e->parity].p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(h.data(), (is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->parity]).p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) host_out[(bc * F + f) * P + p] = h[(bc * T + (T - P + p)) * F + f];
@@ -976,15 +1092,16 @@ int se_import_state(se_engine *e, const char *name, const float *host_in, int64_
             HIPCHECK(e, hipMemcpy(e->hbuf[l][e->hcur[l]].p, host_in + (size_t)l * B * H, (size_t)B * H * sizeof(float), hipMemcpyHostToDevice));
         return SE_OK;
     }
-    if (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L) {
-        const int C = e->Ch[idx], F = e->F[idx], P = 2 << idx;
+    const bool is_pbuf = sscanf(name, "pbuf%d", &idx) == 1 && idx >= 0 && idx < e->npre;
+    if (is_pbuf || (sscanf(name, "buf%d", &idx) == 1 && idx >= 0 && idx < e->L)) {
+        const int C = is_pbuf ? e->Ch[0] : e->Ch[idx], F = is_pbuf ? e->F[0] : e->F[idx], P = is_pbuf ? 4 : (2 << idx);
         if (count != (int64_t)B * C * F * P) return fail(e, SE_ERR_SHAPE, "state %s needs %ld floats", name, (long)B * C * F * P);
         const size_t nsrc = (size_t)B * C * T * F;
         std::vector<float> h(nsrc, 0.0f);
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) h[(bc * T + (T - P + p)) * F + f] = host_in[(bc * F + f) * P + p];
-        HIPCHECK(e, hipMemcpy(e->xin[idx][e->parity].p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy((is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->parity]).p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
         return SE_OK;
     }
     return fail(e, SE_ERR_KEY, "unknown state %s", name);
@@ -995,6 +1112,10 @@ double se_flops_per_frame(const se_engine *e) {
     const int L = e->L, T = e->T, H = e->H, D = e->D;
     double mac = 0;
     for (int i = 0; i < L; i++) mac += (double)e->Ch[i + 1] * e->Ch[i] * 15 * e->F[i + 1] * T;
+    if (e->variant) {
+        for (int i = 0; i < L; i++) mac += 2.0 * e->Ch[i + 1] * e->Ch[i + 1] * e->F[i + 1] * T;  // conv_trans + conv_gated
+        mac += 3.0 * ((double)e->Ch[0] * e->Ch[0] * 25 + 2.0 * e->Ch[0] * e->Ch[0]) * e->F[0] * T;  // preconv blocks
+    }
     for (int j = 0; j < L; j++) {
         const int lvl = L - 1 - j, Ci = e->Ch[lvl + 1], Co = lvl == 0 ? 2 : e->Ch[lvl];
         mac += (double)Ci * Co * 15 * e->F[lvl + 1] * T;

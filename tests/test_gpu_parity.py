@@ -206,3 +206,79 @@ def test_istft_stft_roundtrip_full_batch():
     x = torch.rand(768, 3200, device="cuda") - 0.5
     y = e.istft(e.stft(x))
     assert float((y - x).abs().max()) < 2e-6
+
+
+# ---- a12 / a13: CRN_ELU.py and the distilled-student architecture ------------------------------------------------
+from conftest import STUDENT400, spec_of_variant  # noqa: E402
+
+
+def _engine_v(cfg, variant, seed=0):
+    from speech_enhancement_mi_amd import engine
+    c = engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["segment_length"], cfg["num_layers"],
+                           cfg["num_inputs"], cfg["kernel_size"], cfg["sample_rate"], cfg["win_length"], cfg["hop_length"], cfg["n_fft"],
+                           variant=variant)
+    e = engine.Engine(c, 0)
+    e.load_state_dict(synth.make_state_dict(spec_of_variant(cfg, variant), seed=seed))
+    return e
+
+
+def _oracle_v(cfg, variant, seed=0):
+    from oracle import crn_oracle as orc
+    o = orc.CrnOracle(**cfg, variant=variant)
+    o.load_state_dict(synth.make_state_dict(spec_of_variant(cfg, variant), seed=seed))
+    return o
+
+
+@pytest.mark.parametrize("name,cfg,variant", [("elu_tiny", TINY, 1), ("student_tiny", TINY, 2), ("elu_full", FULL400, 1),
+                                              ("student_full", STUDENT400, 2)])
+def test_variant_forward_stages_vs_oracle(name, cfg, variant):
+    B = 2
+    e, o = _engine_v(cfg, variant), _oracle_v(cfg, variant)
+    mix, _ = synth.synth_utterances(B, 3200 * 3, 3, seed=5)
+    e.reset(B)
+    o.reset(B)
+    F, L = cfg["num_freqs"], len(cfg["num_channels"])
+    for n in range(3):
+        seg = mix[:, :, n * 1600:n * 1600 + 3200]
+        x = o.stft(seg.reshape(-1, 3200)).reshape(B, 3, F, 21, 2)
+        yo = o.forward(x)
+        ye = e.forward(_cuda(x)).cpu().numpy()
+        for tap in ["feat"] + [f"enc{i}" for i in range(L)] + ["gru"] + [f"dec{i}" for i in range(L - 1)]:
+            r = rel_rms(e.read_tap(tap), o.tap(tap))
+            assert r < 2e-5, (name, n, tap, r)
+        assert rel_rms(ye, yo) < TOL, (name, n)
+    assert rel_rms(e.export_state("h"), o.state("h")) < 2e-5
+    for i in range(L):
+        assert rel_rms(e.export_state(f"buf{i}"), o.state(f"buf{i}")) < 2e-5
+    for i in range(3):
+        assert rel_rms(e.export_state(f"pbuf{i}"), o.state(f"pbuf{i}")) < 2e-5
+
+
+@pytest.mark.parametrize("tag,cfg,variant,L,cont", [("elu_tiny", TINY, 1, 8000, 4800), ("student_tiny", TINY, 2, 8000, 4800),
+                                                    ("elu_full400", FULL400, 1, 6400, 0), ("student_full400", STUDENT400, 2, 6400, 0)])
+def test_variant_end_to_end_golden(vgolden, tag, cfg, variant, L, cont):
+    """Against the outputs of the genuine reference CRN_ELU.py / distillation_crn.py modules."""
+    e = _engine_v(cfg, variant)
+    mix, _ = synth.synth_utterances(2, L + cont, 3, seed=7)
+    m = _cuda(mix)
+    y = e.realtime_process(m[..., :L].contiguous()).cpu().numpy()
+    assert rel_rms(y, vgolden[f"{tag}_out"]) < TOL
+    if cont:
+        y2 = e.realtime_process(m[..., L:].contiguous(), flag=True).cpu().numpy()
+        assert rel_rms(y2, vgolden[f"{tag}_cont_out"]) < TOL
+
+
+def test_variant_dropin_classes(vgolden):
+    from speech_enhancement_mi_amd import crn_elu, distillation_crn
+    mix, _ = synth.synth_utterances(2, 6400, 3, seed=7)
+    mt = torch.from_numpy(mix).cuda()
+    m1 = crn_elu.TemporalCRN(**FULL400)
+    m1.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of_variant(FULL400, 1)).items()}, strict=True)
+    y1 = m1.cuda().realtime_process(mt)
+    assert rel_rms(y1.cpu().numpy(), vgolden["elu_full400_out"]) < TOL
+    m2 = distillation_crn.TemporalCRN(**STUDENT400)
+    assert abs(sum(p.numel() for p in m2.parameters()) / 1e6 - 0.812) < 0.005  # README.md:58 "0.81 MB"
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of_variant(STUDENT400, 2)).items()}, strict=True)
+    y2, feats = m2.cuda().realtime_process(mt, flag=False)  # predict_distillation.py:84 unpacks a pair
+    assert feats is None
+    assert rel_rms(y2.cpu().numpy(), vgolden["student_full400_out"]) < TOL
