@@ -50,6 +50,9 @@ struct ConvArgs {
     // (CRN_ELU.py:240: out = conv_trans(out) * sigmoid(conv_gated(out))); the epilogue writes channel c = trans * sigmoid(gated)
     int gate_pairs;
     int Cy, cy0;           // channels of y per stream and channel offset of this launch (row -> channel cy0 + row[/2])
+    // k_conv_small only: fused gated 1x1 pair on the activated outputs (all Co channels of a position live in one
+    // thread): gatew = [trans Co x Co | gated Co x Co | trans bias Co | gated bias Co], nullptr = off
+    const float *gatew;
     // per-workgroup partial (sum, sum of squares) of the stored activations of channels [stats_lo, stats_hi),
     // written to stats[(b*stats_nslot + stats_slot0 + blockIdx.x)*2 + {0,1}] for the global layer norm that
     // follows every block (CRN.py:135-149); nullptr = off.  One slot per workgroup -> deterministic.
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     constexpr int CW = 4 * W4;
     const int nw = NTAP * a.Ci * CW;  // host lays the weights out as ONE chunk: [NTAP][Ci][CW]
     for (int i = tid; i < nw; i += 256) lds[i] = a.w[i];
+    float *gl = lds + nw;
+    const int ng = a.gatew ? 2 * a.Co * a.Co + 2 * a.Co : 0;
+    for (int i = tid; i < ng; i += 256) gl[i] = a.gatew[i];
     __syncthreads();
     const int p = blockIdx.x * 256 + tid;
     const bool live = p < P;
@@ -342,14 +348,38 @@ __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     const long ys_c = (long)a.T * a.Fy;
     float *yp = a.y + ((long)b * a.Cy + a.cy0) * ys_c + (long)t * a.Fy + a.os * m + a.oo;
     float ssum = 0.0f, ssq = 0.0f;
+    float val[CW];
+#pragma unroll
+    for (int co = 0; co < CW; co++) {
+        float v = co < a.Co ? acc[co] + a.bias[co] : 0.0f;
+        if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
+        val[co] = v;
+    }
+    if (a.gatew) {  // out = conv_trans(v) * sigmoid(conv_gated(v))  (CRN_ELU.py:240), channel mixing in registers
+        const int C = a.Co;
+        float outv[CW];
+#pragma unroll
+        for (int co = 0; co < CW; co++) {
+            float tr = 0.0f, gt = 0.0f;
+            if (co < C) {
+                tr = gl[2 * C * C + co];
+                gt = gl[2 * C * C + C + co];
+#pragma unroll
+                for (int j = 0; j < CW; j++)
+                    if (j < C) { tr += gl[co * C + j] * val[j]; gt += gl[C * C + co * C + j] * val[j]; }
+            }
+            outv[co] = tr * (1.0f / (1.0f + expf(-gt)));
+        }
+#pragma unroll
+        for (int co = 0; co < CW; co++) val[co] = outv[co];
+    }
 #pragma unroll
     for (int co = 0; co < CW; co++)
         if (co < a.Co && live) {
-            float v = acc[co] + a.bias[co];
-            if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
-            yp[co * ys_c] = v;
-            if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
+            yp[co * ys_c] = val[co];
+            if (co >= a.stats_lo && co < a.stats_hi) { ssum += val[co]; ssq += val[co] * val[co]; }
         }
+    __syncthreads();  // gl / weights no longer needed: lds doubles as the reduction scratch
     if (a.stats) conv_stats_store(a, ssum, ssq, lds, b);
 }
 

@@ -50,6 +50,7 @@ struct ConvPlan {
     bool active = false;
     bool x6 = false;  // bf16x6 kernel (k_conv_x6) instead of the fp32-MFMA k_conv_igemm
     DevBuf wx;
+    DevBuf gatew;     // k_conv_small: fused gated 1x1 pair weights
     double flops = 0;  // algorithmic FLOPs per stream per launch (SURVEY.md 8d accounting)
 };
 
@@ -473,14 +474,16 @@ int prepare_weights(se_engine *e) {
                            [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * C0 + ci) * 5 + kf) * 5 + kt]; }, *b, 0, C0, 2);
         if (rc) return rc;
         e->lv[i].pre.flops = 2.0 * C0 * C0 * 25 * F0 * e->T;
-        std::vector<float> bias2(2 * C0);
-        for (int c = 0; c < C0; c++) { bias2[2 * c] = (*tb)[c]; bias2[2 * c + 1] = (*gb)[c]; }
-        std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
-        rc = plan_conv(e, e->lv[i].pre_gate, C0, 2 * C0, F0, F0, F0, 1, 1, 0, 0, 0, 1, 0, F0, t1,
-                       [=](int ci, int row, int, int) { const int c = row / 2; return (row & 1) ? gwp[(size_t)c * C0 + ci] : twp[(size_t)c * C0 + ci]; },
-                       bias2, 0, 0, 0, 1, C0, 0);
-        if (rc) return rc;
-        e->lv[i].pre_gate.flops = 2.0 * 2 * C0 * C0 * F0 * e->T;
+        {  // the gated 1x1 pair is fused into the conv's epilogue (all 5 channels of a position sit in one thread)
+            std::vector<float> g;
+            g.insert(g.end(), twp, twp + (size_t)C0 * C0);
+            g.insert(g.end(), gwp, gwp + (size_t)C0 * C0);
+            g.insert(g.end(), tb->begin(), tb->end());
+            g.insert(g.end(), gb->begin(), gb->end());
+            if ((rc = dev_upload(e, e->lv[i].pre.gatew, g))) return rc;
+            e->lv[i].pre.lds += g.size() * sizeof(float);
+            e->lv[i].pre.flops += 2.0 * 2 * C0 * C0 * F0 * e->T;
+        }
         if ((rc = dev_upload(e, e->lv[i].pre_nw, *nw)) || (rc = dev_upload(e, e->lv[i].pre_nb, *nb))) return rc;
     }
     for (int l = 0; l < e->NL; l++) {
@@ -519,7 +522,7 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
     // algorithmic MACs of this launch as SURVEY.md 8d counts them are attributed by the caller via pl.flops
     ProfScope ps(e, pl.x6 ? "k_conv_x6" : (pl.NT == 0 ? "k_conv_small" : "k_conv_igemm"), label, pl.flops * e->B, st);
     ConvArgs a = pl.a;
-    a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p;
+    a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p; a.gatew = pl.gatew.p;
     a.stats = stats; a.stats_nslot = nslot; a.stats_slot0 = slot0; a.stats_lo = stats_lo; a.stats_hi = stats_hi;
     dim3 grid(pl.grid_x, e->B);
     if (pl.x6) {
@@ -613,9 +616,8 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     for (int i = 0; i < e->npre; i++) {  // x = m(x) + x, three frequency-dilated blocks (CRN_ELU.py:375-376)
         const int C0 = e->Ch[0], F0 = e->F[0];
         const long n = (long)C0 * T * F0;
-        if ((rc = launch_conv(e, e->lv[i].pre, e->pin[i][cur].p, e->pin[i][prev].p, e->pre_raw.p, st, ("pre" + std::to_string(i)).c_str()))) return rc;
-        const int ns = e->lv[i].pre_gate.grid_x;
-        if ((rc = launch_conv(e, e->lv[i].pre_gate, e->pre_raw.p, nullptr, e->pre_g.p, st, ("pre_gate" + std::to_string(i)).c_str(),
+        const int ns = e->lv[i].pre.grid_x;
+        if ((rc = launch_conv(e, e->lv[i].pre, e->pin[i][cur].p, e->pin[i][prev].p, e->pre_g.p, st, ("pre" + std::to_string(i)).c_str(),
                               e->pre_stats[i].p, ns, 0, 0, C0))) return rc;
         float *dst = i + 1 < e->npre ? e->pin[i + 1][cur].p : e->xin[0][cur].p;
         if ((rc = launch_gln_ew(e, e->pre_g.p, dst, e->lv[i].pre_nw.p, e->lv[i].pre_nb.p, e->pre_stats[i].p, ns, n, 0, C0, T, F0, st,
@@ -835,7 +837,7 @@ void se_destroy(se_engine *e) {
         dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
         dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]); dev_free(e->enc_g[i]);
-        for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre, &l.pre_gate}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
+        for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre, &l.pre_gate}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); dev_free(p->gatew); }
         dev_free(l.pre_nw); dev_free(l.pre_nb);
         if (i < 3) { dev_free(e->pin[i][0]); dev_free(e->pin[i][1]); dev_free(e->pre_stats[i]); }
     }
@@ -910,7 +912,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             if ((rc = dev_alloc(e, e->pin[i][p], nf))) return rc;
             HIPCHECK(e, hipMemsetAsync(e->pin[i][p].p, 0, nf * sizeof(float), st));
         }
-        if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre_gate.grid_x + 1)))) return rc;
+        if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre.grid_x + 1)))) return rc;
         if ((rc = dev_alloc(e, e->pre_raw, nf)) || (rc = dev_alloc(e, e->pre_g, nf))) return rc;
     }
     if ((rc = dev_alloc(e, e->gru_in, (size_t)B * T * D)) || (rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
