@@ -24,8 +24,8 @@ class CrnCfg(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "crn_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "crn_oracle.c"), os.path.join(_HERE, "fsn_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libcrn_oracle.so"])
     return _SO
 
@@ -101,7 +101,7 @@ class CrnOracle:
         self.B = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().crn_oracle_destroy(self._h)
             self._h = None
 
@@ -206,3 +206,83 @@ def decompress_cirm(m):
     f.argtypes = [C.POINTER(C.c_float), C.c_long, C.POINTER(C.c_float)]
     f(_fp(m), m.size, _fp(out))
     return out
+
+
+# ---- FullSubNet (oracle/fsn_oracle.c) ------------------------------------------------------------------------------
+class FsnCfg(C.Structure):
+    _fields_ = [("num_freqs", C.c_int), ("num_mics", C.c_int), ("fb_hidden", C.c_int), ("sb_hidden", C.c_int),
+                ("num_layers", C.c_int), ("sb_neighbors", C.c_int), ("fb_neighbors", C.c_int), ("look_ahead", C.c_int),
+                ("n_fft", C.c_int), ("win", C.c_int), ("hop", C.c_int), ("segment_length", C.c_int)]
+
+
+class FsnOracle:
+    """Mirror of reference FullSubNet (fullsubnet.py:685-961) on the C restatement; kwargs = config.yaml:153-172."""
+
+    def __init__(self, num_freqs, look_ahead, sequence_model, fb_num_neighbors, sb_num_neighbors, fb_output_activate_function,
+                 sb_output_activate_function, fb_model_hidden_size, sb_model_hidden_size, num_mics, norm_type="offline_laplace_norm",
+                 num_groups_in_drop_band=2, num_layers=2, weight_init=True, sample_rate=16000, segment_length=400, win_length=20,
+                 hop_length=10, n_fft=320):
+        assert sequence_model == "LSTM" and fb_output_activate_function == "ReLU" and not sb_output_activate_function
+        L = lib()
+        fp = C.POINTER(C.c_float)
+        L.fsn_oracle_create.restype = C.c_void_p
+        L.fsn_oracle_create.argtypes = [C.POINTER(FsnCfg)]
+        L.fsn_oracle_destroy.argtypes = [C.c_void_p]
+        L.fsn_oracle_error.restype = C.c_char_p
+        L.fsn_oracle_error.argtypes = [C.c_void_p]
+        L.fsn_oracle_load.argtypes = [C.c_void_p, C.c_char_p, fp, C.POINTER(C.c_int64), C.c_int]
+        L.fsn_oracle_reset.argtypes = [C.c_void_p, C.c_int]
+        L.fsn_oracle_forward.argtypes = [C.c_void_p, fp, fp]
+        L.fsn_oracle_realtime.argtypes = [C.c_void_p, fp, C.c_int, C.c_long, C.c_int, fp]
+        L.fsn_oracle_tap.restype = fp
+        L.fsn_oracle_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
+        cfg = FsnCfg(int(num_freqs), int(num_mics), int(fb_model_hidden_size), int(sb_model_hidden_size), int(num_layers),
+                     int(sb_num_neighbors), int(fb_num_neighbors), int(look_ahead), int(n_fft),
+                     int(round(sample_rate / 1000.0 * win_length)), int(round(sample_rate / 1000.0 * hop_length)), int(segment_length))
+        self.cfg = cfg
+        self._h = L.fsn_oracle_create(C.byref(cfg))
+        if not self._h:
+            raise ValueError("fsn_oracle_create rejected the configuration")
+        self.F, self.M, self.T = cfg.num_freqs, cfg.num_mics, 1 + cfg.segment_length // cfg.hop
+        self.B = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().fsn_oracle_destroy(self._h)
+            self._h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"fsn_oracle error {rc}: {lib().fsn_oracle_error(self._h).decode()}")
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            a = _f32(np.asarray(v))
+            shp = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            self._check(lib().fsn_oracle_load(self._h, k.encode(), _fp(a), shp, a.ndim))
+
+    def reset(self, B):
+        self.B = int(B)
+        lib().fsn_oracle_reset(self._h, self.B)
+
+    def forward(self, x):  # [B, 2M, F, T] -> [B, 2, F, T]
+        x = _f32(x)
+        assert x.shape == (self.B, 2 * self.M, self.F, self.T), x.shape
+        y = np.empty((self.B, 2, self.F, self.T), np.float32)
+        self._check(lib().fsn_oracle_forward(self._h, _fp(x), _fp(y)))
+        return y
+
+    def realtime_process(self, mixture, flag=False):
+        mixture = _f32(mixture)
+        B, M, L = mixture.shape
+        out = np.empty((B, L), np.float32)
+        self._check(lib().fsn_oracle_realtime(self._h, _fp(mixture), B, L, int(bool(flag)), _fp(out)))
+        self.B = B
+        return out
+
+    def tap(self, name):
+        n = C.c_long(0)
+        p = lib().fsn_oracle_tap(self._h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()

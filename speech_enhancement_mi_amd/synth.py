@@ -138,6 +138,20 @@ def crn_param_spec(num_channels, num_freqs, hidden, num_layers=1, num_inputs=3, 
     return spec
 
 
+def fsn_param_spec(num_freqs=201, num_mics=3, fb_hidden=512, sb_hidden=384, num_layers=2, sb_neighbors=15, fb_neighbors=0):
+    """(key, shape) list of reference FullSubNet.state_dict() (fullsubnet.py:728-746; checked against the live module,
+    fixture fsn_keys.json)."""
+    spec = []
+    for name, ins, hid, out in (("fb_model", num_freqs * num_mics, fb_hidden, num_freqs),
+                                ("sb_model", (2 * sb_neighbors + 1) + (2 * fb_neighbors + 1), sb_hidden, 2)):
+        for l in range(num_layers):
+            i = ins if l == 0 else hid
+            spec += [(f"{name}.sequence_model.weight_ih_l{l}", (4 * hid, i)), (f"{name}.sequence_model.weight_hh_l{l}", (4 * hid, hid)),
+                     (f"{name}.sequence_model.bias_ih_l{l}", (4 * hid,)), (f"{name}.sequence_model.bias_hh_l{l}", (4 * hid,))]
+        spec += [(f"{name}.fc_output_layer.weight", (out, hid)), (f"{name}.fc_output_layer.bias", (out,))]
+    return spec
+
+
 def synth_utterances(batch: int, length: int, num_mics: int = 3, seed: int = 0,
                      sample_rate: int = 16000):
     """Synthetic noisy multi-mic speech-like audio: returns (mix [B,M,L], clean [B,L]).

@@ -269,6 +269,35 @@ def main():
     np.savez_compressed(os.path.join(HERE, "crn_variants_golden.npz"), **vout)
     print("wrote crn_variants_golden.npz", os.path.getsize(os.path.join(HERE, "crn_variants_golden.npz")), "bytes;", len(vout), "arrays")
 
+    # ---- a14 / a15: FullSubNet (fullsubnet.py) --------------------------------------------------------------------
+    import fullsubnet as FSN
+    FSN_FULL = dict(num_freqs=201, look_ahead=0, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                    fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                    sb_model_hidden_size=384, num_mics=3, norm_type="offline_laplace_norm", num_groups_in_drop_band=2, num_layers=2,
+                    weight_init=False, sample_rate=16000, segment_length=3200, win_length=25, hop_length=10, n_fft=400)  # config.yaml:153-172
+    FSN_TINY = dict(FSN_FULL, fb_model_hidden_size=16, sb_model_hidden_size=16)
+    fout, fkeys = {}, {}
+    for tag, cfg, B, L, cont in (("fsn_tiny", FSN_TINY, 2, 8000, 4800), ("fsn_full", FSN_FULL, 1, 4800, 0)):
+        model = FSN.FullSubNet(**cfg)
+        model.eval()
+        fkeys[tag] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        sd = synth.make_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        mix, clean = synth.synth_utterances(B, L + cont, 3, seed=7)
+        mix_t = torch.from_numpy(mix)
+        src_t = torch.from_numpy(np.repeat(clean[:, None, :], 3, axis=1).copy())  # only feeds discarded return values
+        with torch.no_grad():
+            y, crm, s_, x_ = model.realtime_process(mix_t[..., :L], src_t[..., :L], flag=False, train=False)
+            fout[f"{tag}_out"] = t2n(y)
+            fout[f"{tag}_crm"] = t2n(crm)[1:3]  # compressed masks of segments 1..2, [2, B, 2, F, T]
+            if cont:
+                y2 = model.realtime_process(mix_t[..., L:], src_t[..., L:], flag=True, train=False)[0]
+                fout[f"{tag}_cont_out"] = t2n(y2)
+    with open(os.path.join(HERE, "fsn_keys.json"), "w") as f:
+        json.dump(fkeys, f, indent=0)
+    np.savez_compressed(os.path.join(HERE, "fsn_golden.npz"), **fout)
+    print("wrote fsn_golden.npz", os.path.getsize(os.path.join(HERE, "fsn_golden.npz")), "bytes")
+
     np.savez_compressed(os.path.join(HERE, "crn_golden.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "crn_golden.npz"))
     print("wrote crn_golden.npz", sz, "bytes;", len(out), "arrays")

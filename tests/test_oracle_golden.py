@@ -141,3 +141,37 @@ def test_variant_full_end_to_end(vgolden, tag, cfg, variant):
     o = _mkv(cfg, variant)
     mix, _ = synth.synth_utterances(2, 6400, 3, seed=7)
     assert rel_rms(o.realtime_process(mix), vgolden[f"{tag}_out"]) < 5e-5
+
+
+# ---- a14 / a15: FullSubNet -------------------------------------------------------------------------------------------
+from conftest import FSN_FULL, FSN_TINY, ROOT, fsn_spec  # noqa: E402
+
+
+def test_fsn_keys_match_reference():
+    import json
+    import os
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fsn_keys.json")))
+    assert [[k, list(s)] for k, s in fsn_spec(FSN_FULL)] == ref["fsn_full"]
+    assert [[k, list(s)] for k, s in fsn_spec(FSN_TINY)] == ref["fsn_tiny"]
+
+
+def _mkf(cfg):
+    o = orc.FsnOracle(**cfg)
+    o.load_state_dict(synth.make_state_dict(fsn_spec(cfg), seed=0))
+    return o
+
+
+def test_fsn_tiny_end_to_end(fgolden):
+    o = _mkf(FSN_TINY)
+    mix, _ = synth.synth_utterances(2, 8000 + 4800, 3, seed=7)
+    y = o.realtime_process(mix[..., :8000])
+    assert rel_rms(y, fgolden["fsn_tiny_out"]) < 2e-5
+    y2 = o.realtime_process(mix[..., 8000:], flag=True)
+    assert rel_rms(y2, fgolden["fsn_tiny_cont_out"]) < 2e-5
+
+
+def test_fsn_full_end_to_end(fgolden):
+    o = _mkf(FSN_FULL)
+    mix, _ = synth.synth_utterances(1, 4800, 3, seed=7)
+    y = o.realtime_process(mix)
+    assert rel_rms(y, fgolden["fsn_full_out"]) < 5e-5
