@@ -113,6 +113,34 @@ int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap,
 
 int se_abi_version(void);
 
+/* ---- FullSubNet (reference fullsubnet.py:685-961; BASELINE config 3) -------------------
+ * Same conventions as the se_* calls above.  Checkpoint keys: fb_model.* / sb_model.* of FullSubNet.state_dict(). */
+typedef struct {
+    int32_t num_freqs, num_mics;
+    int32_t fb_hidden, sb_hidden;       /* fb_model_hidden_size, sb_model_hidden_size */
+    int32_t num_layers;
+    int32_t sb_neighbors, fb_neighbors; /* sb_num_neighbors (15), fb_num_neighbors (0: the only supported value) */
+    int32_t look_ahead;                 /* 0 */
+    int32_t n_fft, win, hop, segment_length;
+} fsn_config;
+
+typedef struct fsn_engine fsn_engine;
+
+/* FullSubNet(**config['FullSubNet'])  (fullsubnet.py:686-767; config.yaml:153-172; LSTM, ReLU / no output activation) */
+int fsn_create(const fsn_config *cfg, int device, fsn_engine **out);
+void fsn_destroy(fsn_engine *e);
+const char *fsn_last_error(const fsn_engine *e);
+int fsn_load_param(fsn_engine *e, const char *key, const float *host_data, const int64_t *shape, int ndim);
+/* reset_state (fullsubnet.py:826-832): zero LSTM states, reset both CumLayerNorm running means */
+int fsn_reset(fsn_engine *e, int batch);
+/* FullSubNet.forward (fullsubnet.py:769-824): x [B, 2M, F, T] (re x M, then im x M) -> compressed mask [B, 2, F, T]; stateful */
+int fsn_forward(fsn_engine *e, const float *x, float *crm, void *stream);
+/* FullSubNet.realtime_process(mixture, source, flag, train=False)[0] (fullsubnet.py:903-961): [B, M, L] -> [B, L] */
+int fsn_realtime_process(fsn_engine *e, const float *mixture, int batch, int64_t length, int flag, float *out, void *stream);
+/* host copies of "fb_out" [B*T, F], "mean_fb" [B], "mean_sb" [B] after the last forward */
+int fsn_read_tap(fsn_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
+double fsn_flops_per_frame(const fsn_engine *e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,281 @@
+// fsn.hip.h - kernels of the FullSubNet path (reference fullsubnet.py:685-961).
+//
+//   k_fsn_mag        |X| of every microphone into the full-band LSTM's input layout [B][T][Kp] (+ partial sums)
+//   k_fsn_scale      CumLayerNorm: x /= running_mean + eps, elementwise (fullsubnet.py:184-201)
+//   k_fsn_runmean    per-stream running-mean update from the partial sums (one thread per stream)
+//   k_lstm_step_x6   one LSTM time step for R rows as a fused GEMM: [x_t | h_{t-1}] . [W_ih | W_hh]^T + b -> gates -> (c, h),
+//                    fp32-accurate bf16x6 MFMA (see gemm.hip.h); the four gate columns of a hidden unit sit in the same
+//                    lane, so the cell update is the epilogue.  Used for both the full-band (R = B) and the sub-band
+//                    (R = B*F = 51 456 at B = 256) models; the latter is 99 % of FullSubNet's 15.5 GFLOP per frame.
+//   k_fsn_unfold     sub-band input: 31 reflect-padded neighbours of the normalised mic-0 magnitude + the full-band
+//                    output, laid out time-major [T][B*F][32] so each step's GEMM operand is contiguous (+ partial sums)
+//   k_fsn_sbfc       Linear(384 -> 2) of the sub-band model for one time step
+//   k_fsn_mask       decompress_cIRM + complex multiply with the mic-0 spectrum (fullsubnet.py:949-953)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm.hip.h"
+#include "norm.hip.h"
+
+namespace se {
+
+// ---- magnitude + partial sums -----------------------------------------------------------------------------------------
+struct FsnMagArgs {
+    const float *re, *im; // element (b, m, t, f) at ptr[b*sB + m*sM + t*sT + f*sF] (float units): interleaved complex spectra
+                          // (im = re + 1) and the reference's planar [B, 2M, F, T] input (fullsubnet.py:835-844) both fit
+    long sB, sM, sT, sF;
+    float *mag;           // [B][T][Kp], column m*F + f; columns >= M*F stay zero
+    float *partial;       // [B][gridDim.x] block sums
+    int M, T, F, Kp;
+};
+
+__global__ __launch_bounds__(256) void k_fsn_mag(FsnMagArgs a) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const int n = a.M * a.T * a.F;
+    float part = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int m = i / (a.T * a.F), r = i - m * a.T * a.F, t = r / a.F, f = r - t * a.F;
+        const long off = (long)b * a.sB + (long)m * a.sM + (long)t * a.sT + (long)f * a.sF;
+        const float vx = a.re[off], vy = a.im[off];
+        const float mg = sqrtf(vx * vx + vy * vy + kEps);  // fullsubnet.py:782
+        a.mag[((long)b * a.T + t) * a.Kp + m * a.F + f] = mg;
+        part += mg;
+    }
+    const double s = block_sum((double)part, red);
+    if (threadIdx.x == 0) a.partial[(long)b * gridDim.x + blockIdx.x] = (float)s;
+}
+
+// run_mean[b] <- first call ? mean : alpha*run_mean + (1-alpha)*mean ; scale[b] = run_mean + eps
+__global__ void k_fsn_runmean(const float *partial, int nslot, double count, float *run_mean, float *denom, int B, int first, float alpha) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0;
+    for (int i = 0; i < nslot; i++) s += (double)partial[(long)b * nslot + i];
+    const float mean = (float)(s / count);
+    const float rm = first ? mean : alpha * run_mean[b] + (1.0f - alpha) * mean;
+    run_mean[b] = rm;
+    denom[b] = rm + kEps;
+}
+
+__global__ void k_fsn_scale(float *x, long per_stream, const float *denom) {
+    const int b = blockIdx.y;
+    const float d = denom[b];
+    float *p = x + (long)b * per_stream;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_stream; i += (long)gridDim.x * blockDim.x) p[i] = p[i] / d;
+}
+
+// ---- sub-band unfold: sbin[t][(b, f)][W + 1] ------------------------------------------------------------------------------
+struct FsnUnfoldArgs {
+    const float *mag;     // normalised [B][T][Kp], mic 0 in columns [0, F)
+    const float *fb_out;  // [B*T][F]  (row b*T + t)
+    float *sbin;          // [T][B*F][SI]
+    float *partial;       // [B][gridDim.x]
+    int B, T, F, Kp, NB, SI;
+};
+
+__global__ __launch_bounds__(256) void k_fsn_unfold(FsnUnfoldArgs a) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const int n = a.T * a.F * a.SI;
+    const int W = 2 * a.NB + 1;
+    float part = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = i / (a.F * a.SI), r = i - t * a.F * a.SI, f = r / a.SI, j = r - f * a.SI;
+        float v;
+        if (j < W) {
+            int fi = f - a.NB + j;  // reflect pad (functional.pad mode="reflect", fullsubnet.py:320)
+            if (fi < 0) fi = -fi;
+            if (fi >= a.F) fi = 2 * (a.F - 1) - fi;
+            v = a.mag[((long)b * a.T + t) * a.Kp + fi];
+        } else {
+            v = a.fb_out[((long)b * a.T + t) * a.F + f];
+        }
+        a.sbin[((long)t * a.B * a.F + (long)b * a.F + f) * a.SI + j] = v;
+        part += v;
+    }
+    const double s = block_sum((double)part, red);
+    if (threadIdx.x == 0) a.partial[(long)b * gridDim.x + blockIdx.x] = (float)s;
+}
+
+// sbin is time-major, so the per-stream scale cannot use k_fsn_scale's contiguous layout
+__global__ void k_fsn_scale_sb(float *sbin, int B, int T, int F, int SI, const float *denom) {
+    const long per_t = (long)B * F * SI, total = per_t * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i % per_t;
+        const int b = (int)(r / ((long)F * SI));
+        sbin[i] = sbin[i] / denom[b];
+    }
+}
+
+// ---- fused LSTM step -----------------------------------------------------------------------------------------------------
+struct LstmStepArgs {
+    const float *x;    // [R][ldx] input of this step (K1 valid columns)
+    long ldx;
+    int K1, K1p;       // K1p = K1 rounded up to a multiple of 32 (weight planes are padded with zeros)
+    const float *hprev;  // [R][H]
+    const __bf16 *Wp;  // [3][4H][K1p + Hp] planes of [W_ih | W_hh], Hp = H rounded up to 32
+    const float *bias; // [4H] = b_ih + b_hh
+    float *c;          // [R][H] cell state, updated in place
+    float *hout;       // [R][H]
+    float *hseq;       // optional second copy of h (row stride ldseq), nullptr = off
+    long ldseq;
+    int R, H;
+};
+
+__global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
+    __shared__ __align__(16) __bf16 Ap[3][kGemmBM * kXLd];
+    __shared__ __align__(16) __bf16 Wl[3][kGemmBN * kXLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * kGemmBM, h0 = blockIdx.x * 32;
+    const int H = a.H, Hp = (H + 31) & ~31, Kt = a.K1p + Hp;
+    const int nck = Kt / kGemmKC;
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[g][r] = 0.0f;
+
+    f32x4 qa[4];
+    uint4 qw[6];
+    auto issue = [&](int ck) {
+        const int k0 = ck * kGemmKC;
+        const bool from_x = k0 < a.K1p;
+        const float *src = from_x ? a.x : a.hprev;
+        const long ld = from_x ? a.ldx : (long)H;
+        const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
+            const int row = min(m0 + r, a.R - 1), k = min(kbase + kq, kval - 4);  // K1, H are multiples of 4 (host-checked)
+            qa[it] = *reinterpret_cast<const f32x4 *>(src + (long)row * ld + k);
+        }
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
+            const int hid = min(h0 + (r & 31), H - 1), wrow = (r >> 5) * H + hid;
+            qw[it] = *reinterpret_cast<const uint4 *>(a.Wp + ((long)plane * 4 * H + wrow) * Kt + k0 + q);
+        }
+    };
+    issue(0);
+    for (int ck = 0; ck < nck; ck++) {
+        const int k0 = ck * kGemmKC;
+        const bool from_x = k0 < a.K1p;
+        const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
+            const bool ok = (m0 + r < a.R) && (kbase + kq < kval);  // 4-aligned windows are either all valid or all padding
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                __bf16 hh, mm, ll;
+                split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
+                h[e] = hh; m[e] = mm; l[e] = ll;
+            }
+            *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
+            *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
+            *reinterpret_cast<bf16x4 *>(&Ap[2][r * kXLd + kq]) = l;
+        }
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
+            const bool ok = h0 + (r & 31) < H;
+            *reinterpret_cast<uint4 *>(&Wl[plane][r * kXLd + q]) = ok ? qw[it] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        if (ck + 1 < nck) issue(ck + 1);
+#pragma unroll
+        for (int ks = 0; ks < kGemmKC; ks += 16) {
+            bf16x8 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const bf16x8 *>(&Ap[p][(wave * 32 + l31) * kXLd + ks + half * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) fb[p] = *reinterpret_cast<const bf16x8 *>(&Wl[p][(g * 32 + l31) * kXLd + ks + half * 8]);
+                f32x16 c = acc[g];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], c, 0, 0, 0);
+                acc[g] = c;
+            }
+        }
+    }
+    // epilogue: torch.nn.LSTM cell, gate order i, f, g, o
+    const int j = h0 + l31;
+    if (j >= H) return;
+    const float bi = a.bias[j], bf = a.bias[H + j], bg = a.bias[2 * H + j], bo = a.bias[3 * H + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= a.R) continue;
+        const float ig = 1.0f / (1.0f + expf(-(acc[0][r] + bi)));
+        const float fg = 1.0f / (1.0f + expf(-(acc[1][r] + bf)));
+        const float gg = tanhf(acc[2][r] + bg);
+        const float og = 1.0f / (1.0f + expf(-(acc[3][r] + bo)));
+        const long idx = (long)m * H + j;
+        const float cn = fg * a.c[idx] + ig * gg;
+        const float hn = og * tanhf(cn);
+        a.c[idx] = cn;
+        a.hout[idx] = hn;
+        if (a.hseq) a.hseq[(long)m * a.ldseq + j] = hn;
+    }
+}
+
+// ---- sub-band Linear(H -> 2) for one time step: one wave per row, lanes across k ---------------------------------------------
+__global__ __launch_bounds__(256) void k_fsn_sbfc(const float *h, const float *w /*[2][H]*/, const float *bias, float *mask /*[R][2][T]*/,
+                                                  int R, int H, int T, int t) {
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wid; row < R; row += nw) {
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int k = lane; k < H; k += 64) {
+            const float v = h[(long)row * H + k];
+            s0 += w[k] * v;
+            s1 += w[H + k] * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
+        if (lane == 0) {
+            mask[((long)row * 2 + 0) * T + t] = s0 + bias[0];
+            mask[((long)row * 2 + 1) * T + t] = s1 + bias[1];
+        }
+    }
+}
+
+// ---- cIRM decompress + complex multiply with mic 0 (fullsubnet.py:949-953) ---------------------------------------------------
+struct FsnMaskArgs {
+    const float *mask;  // [B*F][2][T]
+    const float *re, *im;  // mic-0 spectrum (b, t, f) at ptr[b*sB + t*sT + f*sF] (float units), nullptr = only write crm
+    long sB, sT, sF;
+    cf2 *out;           // (b, t, f) at b*oB + t*oT + f*oF
+    long oB, oT, oF;
+    float *crm;         // optional copy of the compressed mask in the reference layout [B][2][F][T], nullptr = off
+    int T, F;
+};
+
+__global__ void k_fsn_mask(FsnMaskArgs a) {
+    const int b = blockIdx.y;
+    const int TF = a.T * a.F;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TF) return;
+    const int f = i / a.T, t = i - f * a.T;
+    const float cr = a.mask[(((long)b * a.F + f) * 2 + 0) * a.T + t], ci = a.mask[(((long)b * a.F + f) * 2 + 1) * a.T + t];
+    if (a.crm) {
+        a.crm[(((long)b * 2 + 0) * a.F + f) * a.T + t] = cr;
+        a.crm[(((long)b * 2 + 1) * a.F + f) * a.T + t] = ci;
+    }
+    if (!a.re) return;
+    const float mr = decompress_cirm(cr), mi = decompress_cirm(ci);
+    const long off = (long)b * a.sB + (long)t * a.sT + (long)f * a.sF;
+    const float nx = a.re[off], ny = a.im[off];
+    a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * nx - mi * ny, mi * nx + mr * ny};
+}
+
+}  // namespace se

@@ -25,6 +25,7 @@
 #include "../../include/se_engine.h"
 #include "conv_igemm.hip.h"
 #include "conv_x6.hip.h"
+#include "fsn.hip.h"
 #include "fft_lds.h"
 #include "gemm.hip.h"
 #include "norm.hip.h"
@@ -1163,3 +1164,5 @@ int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap,
 }
 
 }  // extern "C"
+
+#include "fsn_engine.inc.h"

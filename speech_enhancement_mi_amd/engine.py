@@ -20,6 +20,8 @@ EXPORTS = [
     "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_step",
     "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
+    "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
+    "fsn_read_tap", "fsn_flops_per_frame",
 ]
 
 
@@ -28,6 +30,12 @@ class SeConfig(C.Structure):
                 ("hidden", C.c_int32), ("num_layers", C.c_int32), ("num_inputs", C.c_int32),
                 ("kernel_size", C.c_int32), ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32),
                 ("segment_length", C.c_int32), ("variant", C.c_int32)]
+
+
+class FsnConfig(C.Structure):
+    _fields_ = [("num_freqs", C.c_int32), ("num_mics", C.c_int32), ("fb_hidden", C.c_int32), ("sb_hidden", C.c_int32),
+                ("num_layers", C.c_int32), ("sb_neighbors", C.c_int32), ("fb_neighbors", C.c_int32), ("look_ahead", C.c_int32),
+                ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32), ("segment_length", C.c_int32)]
 
 
 _lib = None
@@ -63,6 +71,18 @@ def load_library():
     L.se_flops_per_frame.argtypes = [vp]
     L.se_flops_per_frame.restype = C.c_double
     L.se_frames_per_segment.argtypes = [vp]
+    L.fsn_create.argtypes = [C.POINTER(FsnConfig), C.c_int, C.POINTER(vp)]
+    L.fsn_destroy.argtypes = [vp]
+    L.fsn_destroy.restype = None
+    L.fsn_last_error.argtypes = [vp]
+    L.fsn_last_error.restype = C.c_char_p
+    L.fsn_load_param.argtypes = [vp, C.c_char_p, fp, i64p, C.c_int]
+    L.fsn_reset.argtypes = [vp, C.c_int]
+    L.fsn_forward.argtypes = [vp, fp, fp, vp]
+    L.fsn_realtime_process.argtypes = [vp, fp, C.c_int, C.c_int64, C.c_int, fp, vp]
+    L.fsn_read_tap.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
+    L.fsn_flops_per_frame.argtypes = [vp]
+    L.fsn_flops_per_frame.restype = C.c_double
     L.se_profile.argtypes = [vp, C.c_int]
     L.se_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     _lib = L
@@ -222,3 +242,79 @@ class Engine:
     @property
     def flops_per_frame(self) -> float:
         return float(self.lib.se_flops_per_frame(self._h))
+
+
+class FsnEngine:
+    """RAII wrapper over one fsn_engine handle (FullSubNet, fullsubnet.py:685-961)."""
+
+    def __init__(self, num_freqs, num_mics, fb_hidden, sb_hidden, num_layers=2, sb_neighbors=15, fb_neighbors=0, look_ahead=0,
+                 sample_rate=16000, segment_length=3200, win_length=25, hop_length=10, n_fft=400, device=0):
+        self.lib = load_library()
+        cfg = FsnConfig(int(num_freqs), int(num_mics), int(fb_hidden), int(sb_hidden), int(num_layers), int(sb_neighbors),
+                        int(fb_neighbors), int(look_ahead), int(n_fft), int(round(sample_rate / 1000.0 * win_length)),
+                        int(round(sample_rate / 1000.0 * hop_length)), int(segment_length))
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.fsn_create(C.byref(cfg), int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"fsn_create failed ({rc}): {self.lib.fsn_last_error(None).decode()}")
+        self._h = h
+        self.F, self.M, self.K, self.T = cfg.num_freqs, cfg.num_mics, cfg.segment_length, 1 + cfg.segment_length // cfg.hop
+        self.batch = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fsn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"fsn_engine error {rc}: {self.lib.fsn_last_error(self._h).decode()}")
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+            shp = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            self._check(self.lib.fsn_load_param(self._h, k.encode(), C.c_void_p(a.ctypes.data), shp, a.ndim))
+
+    def reset(self, batch):
+        self._check(self.lib.fsn_reset(self._h, int(batch)))
+        self.batch = int(batch)
+
+    def forward(self, x):
+        import torch
+        B = self.batch
+        crm = torch.empty((B, 2, self.F, self.T), dtype=torch.float32, device=x.device)
+        self._check(self.lib.fsn_forward(self._h, Engine._dev(x, (B, 2 * self.M, self.F, self.T)), Engine._dev(crm), Engine._stream()))
+        return crm
+
+    def realtime_process(self, mixture, flag=False, out=None):
+        import torch
+        B, M, L = mixture.shape
+        if M != self.M:
+            raise RuntimeError(f"expected {self.M} microphones, got {M}")
+        if out is None:
+            out = torch.empty((B, L), dtype=torch.float32, device=mixture.device)
+        self._check(self.lib.fsn_realtime_process(self._h, Engine._dev(mixture), B, L, int(bool(flag)), Engine._dev(out, (B, L)), Engine._stream()))
+        self.batch = B
+        return out
+
+    def read_tap(self, name):
+        n = C.c_int64(0)
+        probe = np.empty(1, np.float32)
+        self.lib.fsn_read_tap(self._h, name.encode(), C.c_void_p(probe.ctypes.data), 0, C.byref(n), Engine._stream())
+        if n.value <= 0:
+            self._check(-1)
+        out = np.empty(n.value, np.float32)
+        self._check(self.lib.fsn_read_tap(self._h, name.encode(), C.c_void_p(out.ctypes.data), n.value, C.byref(n), Engine._stream()))
+        return out
+
+    @property
+    def flops_per_frame(self):
+        return float(self.lib.fsn_flops_per_frame(self._h))

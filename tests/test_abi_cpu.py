@@ -12,13 +12,13 @@ from conftest import ROOT
 def _declared():
     text = open(os.path.join(ROOT, "include", "se_engine.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(se_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:se|fsn)_[a-z_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported():
     from speech_enhancement_mi_amd import engine
     names = _declared()
-    assert "se_step" in names and "se_realtime_process" in names and len(names) >= 14
+    assert "se_step" in names and "se_realtime_process" in names and "fsn_realtime_process" in names and len(names) >= 25
     lib = ctypes.CDLL(engine.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in se_engine.h but not exported by libse_engine.so"
