@@ -87,6 +87,58 @@ def pmc_traffic(kernel, args):
     return (2.0 * fetch / nf + write / nw) * 1024.0
 
 
+def bench_fullsubnet(args, rank, local_rank, world):
+    """BASELINE configs[2]: FullSubNet (fb + sb 2-layer LSTM) streaming inference, reference config.yaml:153-172."""
+    import torch
+    import torch.distributed as dist
+    from speech_enhancement_mi_amd import engine, synth
+    spec = synth.fsn_param_spec(201, 3, 512, 384, 2, 15, 0)
+    eng = engine.FsnEngine(201, 3, 512, 384, 2, 15, 0, 0, 16000, 3200, 25, 10, 400, device=local_rank)
+    eng.load_state_dict(synth.make_state_dict(spec, seed=0))
+    B, L = args.batch, int(args.seconds * 16000)
+    base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)
+    mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
+    out = torch.empty((B, L), dtype=torch.float32, device="cuda")
+    P, K = 1600, 3200
+    Lp = L + P
+    gap = K - (P + Lp % K) % K
+    nseg = 2 * (Lp + gap + P) // K
+    for _ in range(args.warmup):
+        eng.realtime_process(mix, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.realtime_process(mix, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all())
+    value = world * B * nseg * args.steps / dt
+    tf = value / world * eng.flops_per_frame / 1e12
+    result = dict(metric="streaming frames/sec @ b256 (FullSubNet, 3200-samp 16 kHz)", value=value, unit="frames/s", n_gpus=world,
+                  steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
+                  vs_baseline=None, dtype="f32", data="synthetic",
+                  config=dict(workload=f"FullSubNet realtime_process(train=False), batch {B} streams/GPU, 400-pt STFT / 201 bins, {args.seconds:g} s "
+                                       f"utterances ({nseg} frames per stream), hash-generated weights", streams_per_gpu=B, frames_per_stream=nseg,
+                              realtime_factor=value * 0.1, mflop_per_frame=eng.flops_per_frame / 1e6),
+                  roofline=dict(bound="mfma", kernel="k_lstm_step_x6", achieved=tf, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=tf / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
+                                note="whole-path rate; the fused sub-band LSTM step GEMM holds 99 % of the FLOPs (bf16x6 MFMA, see DESIGN.md)"),
+                  cpu_baseline=None)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +147,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
     ap.add_argument("--nfft", type=int, default=512, help="512 = BASELINE.json configs[1]; 400 = reference config.yaml default")
     ap.add_argument("--seconds", type=float, default=3.0, help="utterance length")
-    ap.add_argument("--model", choices=sorted(MODELS), default="crn", help="crn = BASELINE.json headline (default)")
+    ap.add_argument("--model", choices=sorted(MODELS) + ["fullsubnet"], default="crn", help="crn = BASELINE.json headline (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,6 +165,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.model == "fullsubnet":
+        return bench_fullsubnet(args, rank, local_rank, world)
     cfg = crn_cfg(args.nfft, args.model)
     variant = MODELS[args.model][0]
     spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=variant)

@@ -347,3 +347,25 @@ def test_fsn_full_end_to_end_golden_and_dropin(fgolden):
     y, crm, s, x = m.cuda().realtime_process(torch.from_numpy(mix).cuda(), src, flag=False, train=False)  # predict_fullsubnet.py:75
     assert crm is None and s is None and x is None
     assert rel_rms(y.cpu().numpy(), fgolden["fsn_full_out"]) < TOL
+
+
+# ---- edge cases the reference's padding logic defines (utility.py:312-336): very short, ragged and boundary lengths ----------
+@pytest.mark.parametrize("L", [1, 7, 1599, 1600, 1601, 3199, 3200, 3201, 4800, 6400])
+def test_edge_lengths_vs_oracle(L):
+    e, o = _engine(TINY), _oracle(TINY)
+    mix, _ = synth.synth_utterances(2, max(L, 64), 3, seed=13)
+    mix = np.ascontiguousarray(mix[..., :L])
+    y = e.realtime_process(_cuda(mix)).cpu().numpy()
+    ref = o.realtime_process(mix)
+    assert y.shape == (2, L)
+    assert np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), L
+
+
+def test_large_batch_and_long_utterance_smoke():
+    """Maximum sizes the benchmark uses and beyond: B = 512 streams, 3.75 s (the reference's max_length, config.yaml:11)."""
+    e = _engine(FULL400)
+    base, _ = synth.synth_utterances(2, 60000, 3, seed=17)
+    big = np.ascontiguousarray(np.tile(base, (256, 1, 1)))
+    y = e.realtime_process(_cuda(big)).cpu().numpy()
+    assert y.shape == (512, 60000) and np.isfinite(y).all()
+    assert np.array_equal(y[0], y[2]) and np.array_equal(y[1], y[511])
