@@ -117,7 +117,7 @@ def bench_fullsubnet(args, rank, local_rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(out).all())
@@ -160,10 +160,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, ndev)  # rehearsal with more ranks than GPUs shares devices (gloo, see below)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world <= ndev:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")  # several ranks per GPU: RCCL refuses duplicate devices
 
     if args.model == "fullsubnet":
         return bench_fullsubnet(args, rank, local_rank, world)
@@ -184,6 +189,8 @@ def main():
     gap = K - (P + Lp % K) % K
     nseg = 2 * (Lp + gap + P) // K
 
+    on_gpu = world > 1 and dist.get_backend() == "nccl"
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -200,7 +207,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(out).all()), "non-finite output"
