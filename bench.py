@@ -87,6 +87,59 @@ def pmc_traffic(kernel, args):
     return (2.0 * fetch / nf + write / nw) * 1024.0
 
 
+def bench_train(args, rank, local_rank, world):
+    """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
+    all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
+    micro-batches, grad accumulation 2 like config.yaml:99), all-reduce, clip, Adam.  value = utterances/s over all ranks."""
+    import torch
+    import torch.distributed as dist
+    from speech_enhancement_mi_amd import synth
+    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN, train_step
+    cfg = crn_cfg(400)  # the reference's training geometry (config.yaml:205-217)
+    model = TrainableCRN(**cfg)
+    spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3)
+    sd = synth.make_state_dict(spec, seed=0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.cuda()
+    bucket = FlatBucket(list(model.parameters()))
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    U, L = args.utts, int(args.seconds * 16000)
+    mix, clean = synth.synth_utterances(U, L, 3, seed=2000 + rank)
+    mix, clean = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
+    on_gpu = world > 1 and dist.get_backend() == "nccl"
+    for _ in range(args.warmup):
+        train_step(model, bucket, opt, mix, clean, accum=2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, bucket, opt, mix, clean, accum=2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert np.isfinite(loss)
+    value = world * U * args.steps / dt
+    result = dict(metric="DP training utterances/sec (TemporalCRN, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
+                  steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
+                  vs_baseline=value / 1.09, dtype="f32", data="synthetic",
+                  config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, torch autograd forward/backward, "
+                                       "flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4; loss = SI-SNR term only (STOI unpinned)",
+                              utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
+                              baseline_note="vs_baseline divides by the reference's 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1) - indicative only"),
+                  roofline=None, cpu_baseline=None)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_fullsubnet(args, rank, local_rank, world):
     """BASELINE configs[2]: FullSubNet (fb + sb 2-layer LSTM) streaming inference, reference config.yaml:153-172."""
     import torch
@@ -148,6 +201,9 @@ def main():
     ap.add_argument("--nfft", type=int, default=512, help="512 = BASELINE.json configs[1]; 400 = reference config.yaml default")
     ap.add_argument("--seconds", type=float, default=3.0, help="utterance length")
     ap.add_argument("--model", choices=sorted(MODELS) + ["fullsubnet"], default="crn", help="crn = BASELINE.json headline (default)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train = BASELINE configs[3]: data-parallel training step (torch autograd + flat-bucket RCCL all-reduce)")
+    ap.add_argument("--utts", type=int, default=8, help="--mode train: utterances per GPU per optimizer step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -170,6 +226,8 @@ def main():
         else:
             dist.init_process_group("gloo")  # several ranks per GPU: RCCL refuses duplicate devices
 
+    if args.mode == "train":
+        return bench_train(args, rank, local_rank, world)
     if args.model == "fullsubnet":
         return bench_fullsubnet(args, rank, local_rank, world)
     cfg = crn_cfg(args.nfft, args.model)

@@ -273,7 +273,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int MT = CoPad / 32;
     if (MT == 3) return fail(e, SE_ERR_ARG, "conv output channels %d need 3 row tiles (unsupported)", Co);
     const int NCG = 4 / MT, NTmax = 4;
-    if (e->conv_mode == 6 && Ci % 8 == 0) {  // ---- bf16x6 path: K step = 2 taps x 8 channels ----
+    if (e->conv_mode == 6 && (Ci % 8 == 0 || Ci >= 5)) {  // ---- bf16x6 path: K step = 2 taps x 8 channels (Cin zero-padded to 8s) ----
         int tpw = 0, n_wg = 0, NT = 0, Rmax = 0, grouped = 0;
         for (int ntmax = NTmax; ntmax >= 1; ntmax--) {
             n_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
@@ -287,7 +287,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
             NT = 0;
         }
         if (NT > 0) {
-            const int npair = (ntap + 1) / 2, nchunk = Ci / 8;
+            const int npair = (ntap + 1) / 2, nchunk = (Ci + 7) / 8;
             ConvArgs &a = pl.a;
             a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
             a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
@@ -304,7 +304,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
                         for (int r = 0; r < 32; r++)
                             for (int k = 0; k < 16; k++) {
                                 const int tp = 2 * pr + k / 8, ci = ch * 8 + k % 8, co = m * 32 + r;
-                                if (tp >= ntap || co >= Co) continue;
+                                if (tp >= ntap || co >= Co || ci >= Ci) continue;
                                 const float x = wsel(ci, co, taps[tp][0], taps[tp][1]);
                                 const uint16_t h = bf16_rne(x);
                                 const float r1 = x - bf16_to_f32(h);
