@@ -456,4 +456,136 @@ __global__ __launch_bounds__(256) void k_gru_step2(GruStepArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All T time steps of one GRU layer in ONE launch.  Same tiling as k_gru_step2 (workgroup = 32 streams x 16 hidden
+// units, W_hh slice resident in LDS) but the slice is loaded ONCE for the T steps instead of once per step, and the
+// kernel boundary between steps is replaced by a hand-off among the 32 workgroups that share the same 32 streams
+// (blockIdx.y): they exchange their 2-KB slices of h_t through global memory.
+// Protocol (cdna_hip_programming.md Guideline 16, recipe R1): every h element is stored write-through with an agent-scope
+// atomic store (global_store_dword sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane
+// adds 1 to the group's counter; before step t every workgroup has ONE lane poll that counter (relaxed, s_sleep) until it
+// reaches 32*t, then ONE agent-scope acquire, s_waitcnt, barrier, and plain vector loads of h_{t-1}.  Results do not
+// depend on dispatch order or XCD placement.  h ping-pongs between two buffers; a workgroup can only start writing
+// step t+1 into the buffer read at step t after all 32 peers published step t, i.e. finished reading it.
+// Residency: a group's 32 workgroups are consecutive block ids (x fastest), one workgroup per CU (LDS), so groups become
+// resident whole, except possibly the last one dispatched, which then waits for CUs freed by finished groups; every
+// spin is bounded and reports through `timeout`.
+struct GruSeqArgs {
+    const float *gi;     // [B][T][3H]
+    const float *h0;     // [B][H] state before step 0 (P0)
+    float *hp0, *hp1;    // ping-pong buffers P0 (== h0) and P1; step t reads (t&1 ? P1 : P0), writes the other
+    const float *whh;    // [3H][H]
+    const float *bhh;    // [3H]
+    float *seq;          // [B][T][H]
+    unsigned *counters;  // [gridDim.y] zeroed before the launch
+    unsigned *timeout;   // set to 1 if a bounded spin gave up
+    int B, H, T;
+};
+
+template <int NKB_HALF>
+__global__ __launch_bounds__(256) void k_gru_seq(GruSeqArgs a) {
+    extern __shared__ __align__(16) f32x4 wlds[];  // [kb][gate][lane]
+    __shared__ float red[2][3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = wave & 1, kh = wave >> 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32 + rt * 16;
+    const int H = a.H, T = a.T;
+    constexpr int NKB = 2 * NKB_HALF;
+    const int arow = min(r0 + l15, a.B - 1);
+    const int n = n0 + l15, nc = min(n, H - 1);
+    const unsigned peers = gridDim.x;
+    unsigned *cnt = a.counters + blockIdx.y;
+    // ---- W_hh slice -> LDS, once ----
+    {
+        constexpr int SLOTS = NKB * 3 * 64 / 256;
+        const float *wrow = a.whh + (long)nc * H + kq * 4;
+        f32x4 qw[SLOTS];
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int s = wave + 4 * j, kb = s / 3, g = s - kb * 3;
+            qw[j] = *reinterpret_cast<const f32x4 *>(wrow + (long)g * H * H + kb * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int s = wave + 4 * j, kb = s / 3, g = s - kb * 3;
+            wlds[(kb * 3 + g) * 64 + lane] = qw[j];
+        }
+    }
+    __syncthreads();
+    const float bh_r = a.bhh[nc], bh_z = a.bhh[H + nc], bh_n = a.bhh[2 * H + nc];
+    for (int t = 0; t < T; t++) {
+        if (t > 0) {  // wait for the 32 slices of h_{t-1}
+            if (tid == 0) {
+                const unsigned target = peers * (unsigned)t;
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) { __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+        const float *hprev = (t & 1) ? a.hp1 : a.hp0;
+        float *hnext = (t & 1) ? a.hp0 : a.hp1;
+        // ---- loads of this step: A fragments (plain vector loads behind the acquire) and epilogue operands ----
+        const float *ap = hprev + (long)arow * H + kq * 4 + kh * NKB_HALF * 16;
+        f32x4 qa[NKB_HALF];
+#pragma unroll
+        for (int i = 0; i < NKB_HALF; i++) qa[i] = *reinterpret_cast<const f32x4 *>(ap + i * 16);
+        float pgi[4][3], php[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = min(r0 + kq * 4 + r, a.B - 1);
+            const float *gi = a.gi + ((long)row * T + t) * 3 * H + nc;
+            pgi[r][0] = gi[0]; pgi[r][1] = gi[H]; pgi[r][2] = gi[2 * H];
+            php[r] = hprev[(long)row * H + nc];
+        }
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NKB_HALF; i++) {
+            const int kb = kh * NKB_HALF + i;
+            const f32x4 c0 = wlds[(kb * 3 + 0) * 64 + lane], c1 = wlds[(kb * 3 + 1) * 64 + lane], c2 = wlds[(kb * 3 + 2) * 64 + lane];
+            const f32x4 ca = qa[i];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e], c0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e], c1[e], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e], c2[e], acc2, 0, 0, 0);
+            }
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                red[rt][0][r][lane] = acc0[r];
+                red[rt][1][r][lane] = acc1[r];
+                red[rt][2][r][lane] = acc2[r];
+            }
+        }
+        __syncthreads();
+        if (kh == 0 && n < H) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = r0 + kq * 4 + r;
+                if (row >= a.B) continue;
+                const float gh_r = acc0[r] + red[rt][0][r][lane] + bh_r;
+                const float gh_z = acc1[r] + red[rt][1][r][lane] + bh_z;
+                const float gh_n = acc2[r] + red[rt][2][r][lane] + bh_n;
+                const float rg = 1.0f / (1.0f + expf(-(pgi[r][0] + gh_r)));
+                const float zg = 1.0f / (1.0f + expf(-(pgi[r][1] + gh_z)));
+                const float ng = tanhf(pgi[r][2] + rg * gh_n);
+                const float hn = (1.0f - zg) * ng + zg * php[r];
+                __hip_atomic_store(hnext + (long)row * H + n, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1)
+                a.seq[((long)row * T + t) * H + n] = hn;  // only read by later launches: a plain store
+            }
+        }
+        // ---- publish this workgroup's slice of h_t ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+        __syncthreads();                                  // ... and `red` may be reused by the next step
+        if (tid == 0 && t + 1 < T) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace se

@@ -77,6 +77,9 @@ struct se_engine {
     bool weights_ready = false;
     size_t conv_lds_budget = 48 * 1024;
     bool gru_direct = false;  // SE_GRU_DIRECT=1: always use the register-streaming step kernel
+    int gru_seq = 0;          // SE_GRU_SEQ=1: one launch per layer (k_gru_seq, in-launch hand-off between steps) instead of one per
+                              // time step (k_gru_step2).  Measured SLOWER on MI355X (17 us vs 13.5 us per step at B=256): off by default
+    DevBuf gru_sync;          // [0,64) group counters, [64] timeout word of k_gru_seq
 
     // constant tables
     DevBuf window, env, tw;
@@ -652,6 +655,24 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     for (int l = 0; l < e->NL; l++) {
         if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
         float *seq = e->seq[l & 1].p;
+        const int ngroup = (B + 31) / 32, nhid = (H + 15) / 16;
+        const bool use_seq = e->gru_seq && !e->gru_direct && (H == 512 || H == 128) && nhid <= 256;
+        if (use_seq) {
+            // groups per launch: all workgroups of a launch must be able to become resident (<= 256 CUs, one per CU)
+            const int gmax = std::max(1, 256 / nhid);
+            for (int g0 = 0; g0 < ngroup; g0 += gmax) {
+                const int ng = std::min(gmax, ngroup - g0), rows0 = g0 * 32, rows = std::min(B - rows0, ng * 32);
+                const int hc = e->hcur[l];
+                HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 64 * sizeof(unsigned), st));
+                GruSeqArgs g{e->gi.p + (long)rows0 * T * 3 * H, e->hbuf[l][hc].p + (long)rows0 * H, e->hbuf[l][hc].p + (long)rows0 * H,
+                             e->hbuf[l][hc ^ 1].p + (long)rows0 * H, e->whh[l].p, e->bhh[l].p, seq + (long)rows0 * T * H,
+                             reinterpret_cast<unsigned *>(e->gru_sync.p), reinterpret_cast<unsigned *>(e->gru_sync.p) + 64, rows, H, T};
+                ProfScope ps(e, "k_gru_seq", "gru_seq", 2.0 * rows * 3 * H * H * T, st);
+                if (H == 512) hipLaunchKernelGGL(k_gru_seq<16>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
+                else hipLaunchKernelGGL(k_gru_seq<4>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
+            }
+            if (T & 1) e->hcur[l] ^= 1;  // the last step (t = T-1) wrote P1 when T is odd, P0 when even
+        } else
         for (int t = 0; t < T; t++) {
             const int hc = e->hcur[l];
             GruStepArgs g{e->gi.p + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
@@ -777,6 +798,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (!e->plan.npass || e->plan.npass > kMaxRadices) return bail(SE_ERR_ARG, "n_fft must factor into 2s and 5s");
     if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
     if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0;
+    if (const char *s = getenv("SE_GRU_SEQ")) e->gru_seq = atoi(s);
     if (const char *s = getenv("SE_GEMM_MODE")) e->gemm_mode = atoi(s);
     if (const char *s = getenv("SE_CONV_MODE")) e->conv_mode = atoi(s);
     if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
@@ -815,6 +837,8 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     SE_X6_ATTR(15) SE_X6_ATTR(9) SE_X6_ATTR(6) SE_X6_ATTR(1)
 #undef SE_X6_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
     *out = e;
     return SE_OK;
@@ -825,7 +849,7 @@ void se_destroy(se_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
-                         &e->fcw_x, &e->pre_raw, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
+                         &e->gru_sync, &e->fcw_x, &e->pre_raw, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
     for (DevBuf *b : singles) dev_free(*b);
     for (int i = 0; i < 4; i++) {
         dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
@@ -925,6 +949,8 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
             HIPCHECK(e, hipMemsetAsync(e->hbuf[l][p].p, 0, (size_t)B * H * sizeof(float), st));
         }
+    if ((rc = dev_alloc(e, e->gru_sync, 128))) return rc;
+    HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 128 * sizeof(float), st));
     for (int l = 0; l < 4; l++) e->hcur[l] = 0;
     e->parity = 0;
     return SE_OK;
