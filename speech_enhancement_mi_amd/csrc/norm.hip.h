@@ -6,11 +6,13 @@
 // the first pass); reductions are wavefront shuffles + one LDS hop, combined in double.
 // Fused variants:
 //   k_featurize  - |X|, arctan phase differences (CRN.py:463-467)
-//   k_gln        - norm + affine, optional re-layout ([C][T][F] <-> GRU's [T][C*F])
-//   k_dec_blend  - decoder skip gate: m = sigmoid(gLN(conv_mask(res))), out = m*relu(conv_res(res)) + (1-m)*pad(gLN(y))
-//                  (CRN.py:387-396)
-//   k_final_mask - gLN of the last decoder block, decompress_cIRM (utility.py:439-442), complex multiply
-//                  with the mic-0 spectrum (CRN.py:491-495)
+//   k_gln           - exact two-pass norm + affine + re-layout, one workgroup per stream (used for the FC output, whose
+//                     producer is a GEMM without per-stream partial statistics)
+//   k_gln_ew        - norm + affine (+ residual add, + re-layout) from the producing conv's partial statistics
+//   k_dec_blend_ew  - decoder skip gate: m = sigmoid(gLN(conv_mask(res))), out = m*act(conv_res(res)) + (1-m)*pad(gLN(y))
+//                     (CRN.py:387-396)
+//   k_final_mask_ew - gLN of the last decoder block, decompress_cIRM (utility.py:439-442), complex multiply
+//                     with the mic-0 spectrum (CRN.py:491-495)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fft_lds.h"
@@ -117,68 +119,10 @@ __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
     }
 }
 
-// ---- decoder skip blend --------------------------------------------------------------------------
-struct BlendArgs {
-    const float *y;   // deconv out, ReLU'd, [B][Co][T][Fo]
-    const float *uv;  // [B][2Co][T][Fr]: u = conv_mask(res) raw, v = relu(conv_res(res))
-    float *out;       // [B][Co][T][Fr]
-    const float *nw, *nb;    // norm affine of y       (deconvlist.j.norm)
-    const float *mnw, *mnb;  // norm affine of u       (deconvlist.j.residualnorm)
-    int Co, T, Fo, Fr;
-};
-
-__global__ __launch_bounds__(1024) void k_dec_blend(BlendArgs a) {
-    __shared__ double red[16];
-    const int b = blockIdx.x;
-    const long ny = (long)a.Co * a.T * a.Fo, nu = (long)a.Co * a.T * a.Fr;
-    const float *y = a.y + b * ny;
-    const float *u = a.uv + (long)b * 2 * nu;
-    const float *v = u + nu;
-    float my, iy, mu, iu;
-    stream_stats(y, ny, red, my, iy);
-    stream_stats(u, nu, red, mu, iu);
-    float *o = a.out + b * nu;
-    const int TFr = a.T * a.Fr;
-    for (long i = threadIdx.x; i < nu; i += blockDim.x) {
-        const int c = (int)(i / TFr), r = (int)(i - (long)c * TFr), t = r / a.Fr, f = r - t * a.Fr;
-        // pad with zeros (after the norm) or crop to the skip's F (CRN.py:389-393)
-        const float yv = f < a.Fo ? (y[((long)c * a.T + t) * a.Fo + f] - my) * iy * a.nw[c] + a.nb[c] : 0.0f;
-        const float uu = (u[i] - mu) * iu * a.mnw[c] + a.mnb[c];
-        const float m = 1.0f / (1.0f + expf(-uu));
-        o[i] = m * v[i] + (1.0f - m) * yv;
-    }
-}
-
-// ---- last decoder block: gLN, decompress cIRM, complex multiply with mic 0 -------------------------
-struct MaskArgs {
-    const float *y;  // [B][2][T][F] ReLU'd deconv output
-    const float *nw, *nb;
-    const cf2 *spec;  // mic-0 spectrum, element (b, t, f) at b*sB + t*sT + f*sF
-    long sB, sT, sF;
-    cf2 *out;  // element (b, t, f) at b*oB + t*oT + f*oF
-    long oB, oT, oF;
-    int T, F;
-};
-
+// ---- cIRM decompression (utility.py:439-442) --------------------------------------------------------------
 __device__ inline float decompress_cirm(float m) {
     m = m >= 9.9f ? 9.9f : (m <= -9.9f ? -9.9f : m);
     return -10.0f * logf((10.0f - m) / (10.0f + m));
-}
-
-__global__ __launch_bounds__(1024) void k_final_mask(MaskArgs a) {
-    __shared__ double red[16];
-    const int b = blockIdx.x;
-    const int TF = a.T * a.F;
-    const float *y = a.y + (long)b * 2 * TF;
-    float mean, inv;
-    stream_stats(y, 2L * TF, red, mean, inv);
-    for (int i = threadIdx.x; i < TF; i += blockDim.x) {
-        const int t = i / a.F, f = i - t * a.F;
-        const float mr = decompress_cirm((y[i] - mean) * inv * a.nw[0] + a.nb[0]);
-        const float mi = decompress_cirm((y[TF + i] - mean) * inv * a.nw[1] + a.nb[1]);
-        const cf2 n = a.spec[(long)b * a.sB + (long)t * a.sT + (long)f * a.sF];
-        a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * n.x - mi * n.y, mi * n.x + mr * n.y};
-    }
 }
 
 // ---- elementwise variants: statistics come from the producing convolution's per-workgroup partials ----------
@@ -331,15 +275,6 @@ __global__ __launch_bounds__(256) void k_final_mask_ew(MaskEwArgs a) {
         const cf2 n = a.spec[(long)b * a.sB + (long)t * a.sT + (long)f * a.sF];
         a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * n.x - mi * n.y, mi * n.x + mr * n.y};
     }
-}
-
-// ---- layout converters for the debug taps / state hand-over ([B][C][T][F] <-> reference [B][C][F][T]) ----
-__global__ void k_ctf_to_cft(const float *src, float *dst, long BC, int T, int F) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC * T * F) return;
-    const long bc = i / ((long)T * F);
-    const int r = (int)(i - bc * T * F), t = r / F, f = r - t * F;
-    dst[(bc * F + f) * T + t] = src[i];
 }
 
 }  // namespace se

@@ -59,7 +59,7 @@ struct Level {  // one encoder/decoder level
     ConvPlan enc;
     ConvPlan dec_even, dec_odd, skip;
     ConvPlan gate[2];      // CRN_ELU encoder: conv_trans/conv_gated 1x1 pair, <= 64 output channels per launch
-    ConvPlan pre, pre_gate; // CRN_ELU preconv block i (levels 0..2): 5x5 frequency-dilated conv + its gated pair
+    ConvPlan pre;          // CRN_ELU preconv block i (levels 0..2): 5x5 frequency-dilated conv with the gated pair fused in
     DevBuf enc_nw, enc_nb, dec_nw, dec_nb, dec_mnw, dec_mnb, pre_nw, pre_nb;
 };
 
@@ -104,8 +104,8 @@ struct se_engine {
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
     DevBuf enc_stats[SE_MAX_LEVELS], dec_stats[SE_MAX_LEVELS], skip_stats[SE_MAX_LEVELS];  // [B][slots][2] norm partials
     DevBuf enc_g[SE_MAX_LEVELS];           // CRN_ELU: gated encoder output before the norm
-    DevBuf pin[3][2], pre_raw, pre_g, pre_stats[3];  // CRN_ELU preconv chain (inputs ping-ponged: they carry 4 history columns)
-    DevBuf yseg, scratch;
+    DevBuf pin[3][2], pre_g, pre_stats[3];  // CRN_ELU preconv chain (inputs ping-ponged: they carry 4 history columns)
+    DevBuf yseg;
 
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
@@ -849,7 +849,7 @@ void se_destroy(se_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
-                         &e->gru_sync, &e->fcw_x, &e->pre_raw, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg, &e->scratch};
+                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
     for (int i = 0; i < 4; i++) {
         dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
@@ -862,7 +862,7 @@ void se_destroy(se_engine *e) {
         dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
         dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]); dev_free(e->enc_g[i]);
-        for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre, &l.pre_gate}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); dev_free(p->gatew); }
+        for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); dev_free(p->gatew); }
         dev_free(l.pre_nw); dev_free(l.pre_nb);
         if (i < 3) { dev_free(e->pin[i][0]); dev_free(e->pin[i][1]); dev_free(e->pre_stats[i]); }
     }
@@ -938,7 +938,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             HIPCHECK(e, hipMemsetAsync(e->pin[i][p].p, 0, nf * sizeof(float), st));
         }
         if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre.grid_x + 1)))) return rc;
-        if ((rc = dev_alloc(e, e->pre_raw, nf)) || (rc = dev_alloc(e, e->pre_g, nf))) return rc;
+        if ((rc = dev_alloc(e, e->pre_g, nf))) return rc;
     }
     if ((rc = dev_alloc(e, e->gru_in, (size_t)B * T * D)) || (rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
         (rc = dev_alloc(e, e->seq[0], (size_t)B * T * H)) || (rc = dev_alloc(e, e->seq[1], (size_t)B * T * H)) ||
