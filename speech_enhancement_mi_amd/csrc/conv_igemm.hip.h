@@ -88,6 +88,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
     const long ys_c = (long)a.T * a.Fy;
     float *yb = a.y + ((long)b * a.Cy + a.cy0) * ys_c;
     float ssum = 0.0f, ssq = 0.0f;
+    // the 16 biases of this lane's rows are fetched ONCE, ahead of all stores: a bias load between two stores cannot be
+    // hoisted by the compiler (y may alias bias for all it knows) and would cost one L1 round trip per stored element
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bv[r] = a.bias[min(co, a.Co - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) asm volatile("" : "+v"(bv[r]));
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         if (!lane_ok[i]) continue;
@@ -97,7 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
             for (int r = 0; r < 16; r += 2) {
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // even
                 if (row + 1 < a.Co) {
-                    const float tr = acc[i][r] + a.bias[row], gt = acc[i][r + 1] + a.bias[row + 1];
+                    const float tr = acc[i][r] + bv[r], gt = acc[i][r + 1] + bv[r + 1];
                     const float v = tr * (1.0f / (1.0f + expf(-gt)));
                     yp[(row >> 1) * ys_c] = v;
                     ssum += v; ssq += v * v;
@@ -108,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
             for (int r = 0; r < 16; r++) {
                 const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < a.Co) {
-                    float v = acc[i][r] + a.bias[co];
+                    float v = acc[i][r] + bv[r];
                     if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
                     yp[co * ys_c] = v;
                     if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }

@@ -24,6 +24,9 @@ constexpr int kX6PosPerThread = 4;  // patch positions (row, col) per thread: R*
 struct ConvX6Args {
     ConvArgs c;        // geometry, x / xprev / bias / y / stats exactly as for k_conv_igemm (c.w unused, c.CC == 8)
     const uint4 *wx;   // [nchunk][npair][3][MT][64] fragments of 16 B
+#ifdef SE_X6_TRACE
+    int trace_slot;
+#endif
 };
 
 __device__ __forceinline__ uint4 pack_bf16x8(const __bf16 (&v)[8]) {
@@ -32,6 +35,13 @@ __device__ __forceinline__ uint4 pack_bf16x8(const __bf16 (&v)[8]) {
     for (int i = 0; i < 8; i++) t[i] = v[i];
     return __builtin_bit_cast(uint4, t);
 }
+
+#ifdef SE_X6_TRACE
+__device__ unsigned long long g_x6_trace[16];
+#define X6T(i) do { const unsigned long long _n = __builtin_readcyclecounter(); if (tid == 0) tr[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define X6T(i)
+#endif
 
 template <int NTAP, int NT>
 __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
@@ -52,16 +62,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
     const int mt = wave % MT, cg = wave / MT;
     const int half = lane >> 5, l31 = lane & 31;
 
-    int lane_base[NT], pos_t[NT], pos_m[NT];
-    bool lane_ok[NT];
+    int lane_base[NT];  // (the epilogue's position bookkeeping is recomputed after the loop: it would only hold registers)
 #pragma unroll
     for (int i = 0; i < NT; i++) {
-        const int p = p0 + (cg + i * NCG) * 32 + l31;
-        lane_ok[i] = p < p1;
-        const int pc = lane_ok[i] ? p : (p1 - 1);
+        const int pc = min(p0 + (cg + i * NCG) * 32 + l31, p1 - 1);
         const int t = pc / a.FP, m = pc - t * a.FP;
-        pos_t[i] = t;
-        pos_m[i] = m;
         lane_base[i] = (t - ta) * St + a.s * m;
     }
     int toffL[NPAIR];  // per lane half: position offset of tap 2*pair + half
@@ -116,8 +121,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
     const uint4 *wxw = xa.wx + (long)mt * 64 + l31 * 2 + half;  // + (((ch*NPAIR + pr)*3 + plane)*MT) * 64
     const long wx_plane = (long)MT * 64, wx_pair = 3 * wx_plane, wx_chunk = NPAIR * wx_pair;
 
+#ifdef SE_X6_TRACE
+    unsigned long long tr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int ch = 0; ch < a.nchunk; ch++) {
+        X6T(0);
         __syncthreads();  // previous chunk fully consumed
+        X6T(1);
+#ifdef SE_X6_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X6T(2);
+#endif
 #pragma unroll
         for (int k = 0; k < kX6PosPerThread; k++) {
             const int pe = tid + 256 * k;
@@ -131,12 +145,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
                 planes[2 * Npos + pe] = pack_bf16x8(l);
             }
         }
+        X6T(3);
         __syncthreads();
-        if (ch + 1 < a.nchunk) issue_loads(ch + 1);  // in flight during the MFMAs below
+        X6T(4);
         const uint4 *wc = wxw + ch * wx_chunk;
         uint4 fa_n[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) fa_n[p] = wc[p * wx_plane];
+#ifdef SE_X6_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X6T(5);
+#endif
 #pragma unroll
         for (int pr = 0; pr < NPAIR; pr++) {
             bf16x8 fa[3];
@@ -146,6 +165,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
 #pragma unroll
                 for (int p = 0; p < 3; p++) fa_n[p] = wc[(pr + 1) * wx_pair + p * wx_plane];
             }
+            // vmcnt retires in order: the next chunk's 32 staging loads are issued only after the LAST weight-fragment
+            // load of this chunk, otherwise the first in-loop fragment wait would also wait for all of them
+            if (pr == (NPAIR >= 2 ? NPAIR - 2 : 0) && ch + 1 < a.nchunk) issue_loads(ch + 1);
 #pragma unroll
             for (int i = 0; i < NT; i++) {
                 const int pos = lane_base[i] + toffL[pr];
@@ -163,8 +185,47 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
             }
         }
     }
+    X6T(0);
     __syncthreads();
+    X6T(1);
+#ifdef SE_X6_TRACE
+    {
+        int pos_t[NT], pos_m[NT];
+        bool lane_ok[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int p = p0 + (cg + i * NCG) * 32 + l31;
+            lane_ok[i] = p < p1;
+            const int pc = lane_ok[i] ? p : (p1 - 1);
+            pos_t[i] = pc / a.FP;
+            pos_m[i] = pc - pos_t[i] * a.FP;
+        }
+        ConvArgs a2 = a;
+        a2.stats = nullptr;
+        conv_epilogue<NT>(a2, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b);
+        X6T(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X6T(7);
+        if (a.stats) conv_stats_store(a, 0.f, 0.f, reinterpret_cast<float *>(planes), b);
+        X6T(8);
+    }
+    if (tid == 0 && xa.trace_slot >= 0) {
+        for (int i = 0; i < 9; i++) atomicAdd(&g_x6_trace[i], tr[i]);
+        atomicAdd(&g_x6_trace[15], 1ull);
+    }
+#else
+    int pos_t[NT], pos_m[NT];
+    bool lane_ok[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int p = p0 + (cg + i * NCG) * 32 + l31;
+        lane_ok[i] = p < p1;
+        const int pc = lane_ok[i] ? p : (p1 - 1);
+        pos_t[i] = pc / a.FP;
+        pos_m[i] = pc - pos_t[i] * a.FP;
+    }
     conv_epilogue<NT>(a, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b);
+#endif
 }
 
 }  // namespace se

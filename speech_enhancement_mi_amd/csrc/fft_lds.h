@@ -17,7 +17,7 @@
 #endif
 #endif
 
-struct cf2 {
+struct alignas(8) cf2 {
     float x, y;
 };
 

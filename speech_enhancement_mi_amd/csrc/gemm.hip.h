@@ -84,13 +84,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(GemmArgs a) {
         }
     }
     // D layout: column (n) on lanes, rows (m) in registers
+    float bsj[2];  // fetched ahead of all stores (a load between stores cannot be hoisted: C may alias bias)
+#pragma unroll
+    for (int j = 0; j < 2; j++) bsj[j] = a.bias ? a.bias[min(n0 + wn + j * 32 + l31, a.N - 1)] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int n = n0 + wn + j * 32 + l31;
             if (n >= a.N) continue;
-            const float bs = a.bias ? a.bias[n] : 0.0f;
+            const float bs = bsj[j];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -216,13 +219,16 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
                 }
         }
     }
+    float bsj[2];  // fetched ahead of all stores (a load between stores cannot be hoisted: C may alias bias)
+#pragma unroll
+    for (int j = 0; j < 2; j++) bsj[j] = a.bias ? a.bias[min(n0 + wn + j * 32 + l31, a.N - 1)] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int n = n0 + wn + j * 32 + l31;
             if (n >= a.N) continue;
-            const float bs = a.bias ? a.bias[n] : 0.0f;
+            const float bs = bsj[j];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;

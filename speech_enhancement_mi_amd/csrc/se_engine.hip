@@ -42,6 +42,9 @@ struct DevBuf {
     size_t n = 0;
 };
 
+constexpr int kPipeChunk = 64;  // segments per pipelined chunk (bounds spec_all / mask_all)
+constexpr int kRing = 4;  // stage-crossing activation slots (see se_engine::slot)
+
 struct ConvPlan {
     ConvArgs a{};  // pointers filled per launch
     int NT = 1;
@@ -52,6 +55,9 @@ struct ConvPlan {
     bool x6 = false;  // bf16x6 kernel (k_conv_x6) instead of the fp32-MFMA k_conv_igemm
     DevBuf wx;
     DevBuf gatew;     // k_conv_small: fused gated 1x1 pair weights
+    // k_conv_x6 tilings that fit (index = tiles per wave - 1); the weights do not depend on the tiling, so the one that
+    // fills the chip with the fewest partial rounds is picked per batch size in select_conv_geometry()
+    struct Geo { int NT = 0, tpw = 0, n_wg = 0, grouped = 0; size_t lds = 0; } geo[4];
     double flops = 0;  // algorithmic FLOPs per stream per launch (SURVEY.md 8d accounting)
 };
 
@@ -91,15 +97,27 @@ struct se_engine {
     DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
+    int num_cu = 256;         // compute units of the device (MI355X: 256)
+    int conv_geo_fixed = 0;   // SE_CONV_GEO_FIXED=1: always the largest k_conv_x6 tiling (no per-batch selection)
     int conv_mode = 6;        // SE_CONV_MODE: 0 = fp32 MFMA (k_conv_igemm), 6 = bf16x6 where Cin % 8 == 0 (default)
 
     // state + activations for B streams
     int B = 0;
-    int parity = 0;  // index of the "current" ping-pong half
-    DevBuf spec, maskspec;
-    DevBuf xin[SE_MAX_LEVELS][2];  // encoder level inputs (xin[0] = features), ping-pong
+    int parity = 0;  // index of the "current" half of the encoder-private ping-pong buffers (pin)
+    // Buffers that cross the three stages of a segment (encoder -> recurrent bottleneck -> decoder) live in a ring of
+    // kRing slots, so that in se_realtime_process the encoder of segment n+1.. can run on its own HIP stream while the
+    // latency-bound GRU recurrence of segment n and the decoder of segment n-1 are still in flight.  slot = segment % kRing;
+    // xin[i][slot-1] doubles as the causal time history of the level-i convolution (CRN.py:333-334).
+    int slot = 0;
+    DevBuf spec[kRing], maskspec;
+    DevBuf spec_all, mask_all;         // pipelined se_realtime_process: spectra / masked spectra of one chunk of segments
+    DevBuf xin[SE_MAX_LEVELS][kRing];  // encoder level inputs (xin[0] = features)
     DevBuf enc_raw[SE_MAX_LEVELS];
-    DevBuf gru_in, gi, seq[2], hbuf[4][2], fc_out, dec_in;
+    DevBuf gru_in[kRing], gi, seq[2], hbuf[4][2], fc_out, dec_in[kRing];
+    int pipeline = 1;                  // SE_PIPELINE=0: one stream, stages back to back
+    hipStream_t stage_stream[3]{};     // encoder / bottleneck / decoder
+    hipEvent_t ev_enc[kRing]{}, ev_gru[kRing]{}, ev_dec[kRing]{}, ev_fork{}, ev_join{};
+    bool stage_ready = false;
     int hcur[4]{};
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
     DevBuf enc_stats[SE_MAX_LEVELS], dec_stats[SE_MAX_LEVELS], skip_stats[SE_MAX_LEVELS];  // [B][slots][2] norm partials
@@ -278,16 +296,20 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int NCG = 4 / MT, NTmax = 4;
     if (e->conv_mode == 6 && (Ci % 8 == 0 || Ci >= 5)) {  // ---- bf16x6 path: K step = 2 taps x 8 channels (Cin zero-padded to 8s) ----
         int tpw = 0, n_wg = 0, NT = 0, Rmax = 0, grouped = 0;
-        for (int ntmax = NTmax; ntmax >= 1; ntmax--) {
-            n_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
-            tpw = (tiles + n_wg - 1) / n_wg;
-            NT = (tpw + NCG - 1) / NCG;
-            int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
+        for (int k = 0; k < 4; k++) pl.geo[k] = ConvPlan::Geo{};
+        for (int ntmax = 1; ntmax <= NTmax; ntmax++) {  // ends on the largest tiling that fits = the default geometry
+            const int c_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
+            const int c_tpw = (tiles + c_wg - 1) / c_wg;
+            const int c_NT = (c_tpw + NCG - 1) / NCG;
+            int rows_pos = (c_tpw * 32 + FP - 1) / FP + 1;
             if (rows_pos > T) rows_pos = T;
-            grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
-            Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
-            if ((size_t)Rmax * St <= 256 * kX6PosPerThread) break;
-            NT = 0;
+            const int c_grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+            const int c_Rmax = c_grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
+            if ((size_t)c_Rmax * St > 256 * kX6PosPerThread) continue;
+            ConvPlan::Geo &g = pl.geo[c_NT - 1];
+            g.NT = c_NT; g.tpw = c_tpw; g.n_wg = c_wg; g.grouped = c_grouped;
+            g.lds = std::max<size_t>((size_t)3 * c_Rmax * St * 16, 64);
+            tpw = c_tpw; n_wg = c_wg; NT = c_NT; Rmax = c_Rmax; grouped = c_grouped;
         }
         if (NT > 0) {
             const int npair = (ntap + 1) / 2, nchunk = (Ci + 7) / 8;
@@ -520,6 +542,29 @@ int prepare_weights(se_engine *e) {
     return 0;
 }
 
+// Picks, for the current batch, the k_conv_x6 tiling with the least modelled time.  Measured on MI355X (NT sweep,
+// profiles/r01_v4_conv_nt_sweep.txt): a workgroup costs ~(NT + 0.28) units (the constant is the first weight fragments and
+// the barriers), and a partial last round of resident workgroups costs about its share (a workgroup alone on a CU gets the
+// matrix pipe to itself), so time ~ workgroups x (NT + 0.28), quantised only when the whole launch is below one round.
+void select_conv_geometry(se_engine *e, ConvPlan &pl) {
+    if (!pl.active || !pl.x6) return;
+    const double slots = 2.0 * e->num_cu;
+    double best = 0;
+    int pick = -1;
+    for (int k = 0; k < 4; k++) {
+        const ConvPlan::Geo &g = pl.geo[k];
+        if (!g.NT) continue;
+        const double rounds = std::max(1.0, (double)g.n_wg * e->B / slots);
+        const double cost = rounds * (g.NT + 0.28);
+        if (pick < 0 || cost <= best) { best = cost; pick = k; }
+    }
+    if (e->conv_geo_fixed) for (int k = 3; k >= 0; k--) if (pl.geo[k].NT) { pick = k; break; }
+    if (const char *s = getenv("SE_CONV_NT")) { const int k = atoi(s) - 1; if (k >= 0 && k < 4 && pl.geo[k].NT) pick = k; }
+    const ConvPlan::Geo &g = pl.geo[pick];
+    pl.NT = g.NT; pl.grid_x = g.n_wg; pl.lds = g.lds;
+    pl.a.tiles_per_wg = g.tpw; pl.a.grouped = g.grouped;
+}
+
 int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st, const char *label,
                 float *stats = nullptr, int nslot = 0, int slot0 = 0, int stats_lo = 0, int stats_hi = 0) {
     if (!pl.active) return 0;
@@ -531,6 +576,9 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
     dim3 grid(pl.grid_x, e->B);
     if (pl.x6) {
         ConvX6Args xa{a, reinterpret_cast<const uint4 *>(pl.wx.p)};
+#ifdef SE_X6_TRACE
+        { const char *want = getenv("SE_X6_TRACE_LABEL"); xa.trace_slot = (want && label && strcmp(want, label) == 0) ? 0 : -1; }
+#endif
 #define SE_X6_CASE(NTAP_, NT_) \
     case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_>), grid, dim3(256), pl.lds, st, xa); break;
 #define SE_X6_TAPS(NTAP_) SE_X6_CASE(NTAP_, 1) SE_X6_CASE(NTAP_, 2) SE_X6_CASE(NTAP_, 3) SE_X6_CASE(NTAP_, 4)
@@ -602,16 +650,17 @@ int launch_gln_ew(se_engine *e, const float *x, float *y, const float *w, const 
     return 0;
 }
 
-// TemporalCRN.forward on device.  spec: (b, m, t, f) strides; out: (b, t, f) strides (cf2 units).
-int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long sF, cf2 *out, long oB, long oT, long oF,
-                hipStream_t st) {
-    const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+// TemporalCRN.forward on device in three stages; each reads/writes the ring slot `cur` (history from slot `prev`).
+// spec: (b, m, t, f) strides; out: (b, t, f) strides (cf2 units).
+// Stage 1: features + (CRN_ELU pre-convs) + encoder  ->  xin[*][cur], gru_in[cur]
+int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
+    const int L = e->L, T = e->T, B = e->B;
     int rc;
     e->parity ^= 1;
-    const int cur = e->parity, prev = cur ^ 1;
+    const int pcur = e->parity, pprev = pcur ^ 1;
     {  // features (CRN.py:463-467)
         ProfScope ps(e, "k_featurize", "featurize", 0, st);
-        float *dst = e->npre ? e->pin[0][cur].p : e->xin[0][cur].p;
+        float *dst = e->npre ? e->pin[0][pcur].p : e->xin[0][cur].p;
         FeatArgs f{spec, sB, sM, sT, sF, dst, e->M, T, e->F[0], e->atan2_phase};
         const int TF = T * e->F[0];
         hipLaunchKernelGGL(k_featurize, dim3((TF + 255) / 256, B), dim3(256), 0, st, f);
@@ -621,11 +670,11 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
         const int C0 = e->Ch[0], F0 = e->F[0];
         const long n = (long)C0 * T * F0;
         const int ns = e->lv[i].pre.grid_x;
-        if ((rc = launch_conv(e, e->lv[i].pre, e->pin[i][cur].p, e->pin[i][prev].p, e->pre_g.p, st, ("pre" + std::to_string(i)).c_str(),
+        if ((rc = launch_conv(e, e->lv[i].pre, e->pin[i][pcur].p, e->pin[i][pprev].p, e->pre_g.p, st, ("pre" + std::to_string(i)).c_str(),
                               e->pre_stats[i].p, ns, 0, 0, C0))) return rc;
-        float *dst = i + 1 < e->npre ? e->pin[i + 1][cur].p : e->xin[0][cur].p;
+        float *dst = i + 1 < e->npre ? e->pin[i + 1][pcur].p : e->xin[0][cur].p;
         if ((rc = launch_gln_ew(e, e->pre_g.p, dst, e->lv[i].pre_nw.p, e->lv[i].pre_nb.p, e->pre_stats[i].p, ns, n, 0, C0, T, F0, st,
-                                e->pin[i][cur].p))) return rc;
+                                e->pin[i][pcur].p))) return rc;
     }
     for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474; CRN_ELU.py:233-247)
         const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
@@ -646,11 +695,17 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
             normed_src = e->enc_g[i].p;
         }
         if (i + 1 < L) rc = launch_gln_ew(e, normed_src, e->xin[i + 1][cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 0, Co, T, Fo, st);
-        else rc = launch_gln_ew(e, normed_src, e->gru_in.p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 1, Co, T, Fo, st);
+        else rc = launch_gln_ew(e, normed_src, e->gru_in[cur].p, e->lv[i].enc_nw.p, e->lv[i].enc_nb.p, e->enc_stats[i].p, ns, n, 1, Co, T, Fo, st);
         if (rc) return rc;
     }
-    // bottleneck (CRN.py:476-481, 256-282)
-    const float *layer_in = e->gru_in.p;
+    return 0;
+}
+
+// Stage 2: the recurrent bottleneck (CRN.py:476-481, 256-282)  gru_in[cur] -> dec_in[cur]
+int stage_bottleneck(se_engine *e, int cur, hipStream_t st) {
+    const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+    int rc;
+    const float *layer_in = e->gru_in[cur].p;
     long in_dim = D;
     for (int l = 0; l < e->NL; l++) {
         if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
@@ -689,9 +744,14 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
         in_dim = H;
     }
     if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
-    if ((rc = launch_gln(e, e->fc_out.p, e->dec_in.p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st))) return rc;
-    // decoder (CRN.py:483-489)
-    const float *x = e->dec_in.p;
+    return launch_gln(e, e->fc_out.p, e->dec_in[cur].p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st);
+}
+
+// Stage 3: decoder (CRN.py:483-489) + mask application  dec_in[cur], xin[*][cur], spec -> out
+int stage_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long sF, cf2 *out, long oB, long oT, long oF, hipStream_t st) {
+    const int L = e->L, T = e->T, B = e->B;
+    int rc;
+    const float *x = e->dec_in[cur].p;
     for (int j = 0; j < L; j++) {
         const int lvl = L - 1 - j;
         const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1], Fo = 2 * Fi - 1;
@@ -724,6 +784,16 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     return 0;
 }
 
+int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long sF, cf2 *out, long oB, long oT, long oF,
+                hipStream_t st) {
+    const int prev = e->slot, cur = (e->slot + 1) % kRing;
+    e->slot = cur;
+    int rc;
+    if ((rc = stage_encoder(e, cur, prev, spec, sB, sM, sT, sF, st))) return rc;
+    if ((rc = stage_bottleneck(e, cur, st))) return rc;
+    return stage_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
+}
+
 int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int M, long off, long Lsrc, int rows,
                 cf2 *spec, long sR, long sT, long sF, hipStream_t st) {
     StftArgs a{};
@@ -750,7 +820,14 @@ int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int r
 int ensure_ready(se_engine *e) {
     if (!e) return SE_ERR_ARG;
     HIPCHECK(e, hipSetDevice(e->device));
-    return prepare_weights(e);
+    const bool replanned = !e->weights_ready;
+    int rc = prepare_weights(e);
+    if (rc) return rc;
+    if (replanned && e->B > 0)  // new weights re-made the plans with their default tiling: restore the per-batch choice
+        for (int i = 0; i < SE_MAX_LEVELS; i++)
+            for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
+                select_conv_geometry(e, *p);
+    return 0;
 }
 
 }  // namespace
@@ -801,6 +878,12 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_GRU_SEQ")) e->gru_seq = atoi(s);
     if (const char *s = getenv("SE_GEMM_MODE")) e->gemm_mode = atoi(s);
     if (const char *s = getenv("SE_CONV_MODE")) e->conv_mode = atoi(s);
+    if (const char *s = getenv("SE_CONV_GEO_FIXED")) e->conv_geo_fixed = atoi(s);
+    if (const char *s = getenv("SE_PIPELINE")) e->pipeline = atoi(s);
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) e->num_cu = ncu;
+    }
     if (hipSetDevice(device) != hipSuccess) return bail(SE_ERR_HIP, "hipSetDevice failed");
     // tables: hamming(win) centred in n_fft (torch.stft), twiddles, overlap-add envelope
     const int N = e->N, T = e->T, hop = cfg->hop, K = e->K;
@@ -848,9 +931,29 @@ void se_destroy(se_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
-    DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->spec, &e->maskspec,
-                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->gru_in, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->dec_in, &e->yseg};
+#ifdef SE_X6_TRACE
+    {
+        unsigned long long t[16] = {0};
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_x6_trace), sizeof(t));
+        if (t[15]) {
+            const char *nm[9] = {"prologue + pair loops", "barrier1", "wait staging loads", "split+lds write", "barrier2", "first A frag", "epilogue issue", "epilogue store drain", "stats reduce"};
+            fprintf(stderr, "[x6 trace %s] %llu WG-samples\n", getenv("SE_X6_TRACE_LABEL"), t[15]);
+            for (int i = 0; i < 9; i++) fprintf(stderr, "   %-28s %10.0f cycles/WG\n", nm[i], (double)t[i] / t[15]);
+        }
+    }
+#endif
+    DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->maskspec,
+                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->spec_all, &e->mask_all, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
+    for (int r = 0; r < kRing; r++) {
+        dev_free(e->spec[r]); dev_free(e->gru_in[r]); dev_free(e->dec_in[r]);
+        for (int i = 0; i < SE_MAX_LEVELS; i++) dev_free(e->xin[i][r]);
+        if (e->stage_ready) { (void)hipEventDestroy(e->ev_enc[r]); (void)hipEventDestroy(e->ev_gru[r]); (void)hipEventDestroy(e->ev_dec[r]); }
+    }
+    if (e->stage_ready) {
+        (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join);
+        for (hipStream_t q : e->stage_stream) (void)hipStreamDestroy(q);
+    }
     for (int i = 0; i < 4; i++) {
         dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
         dev_free(e->hbuf[i][0]); dev_free(e->hbuf[i][1]);
@@ -859,7 +962,7 @@ void se_destroy(se_engine *e) {
         Level &l = e->lv[i];
         for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
         for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
-        dev_free(e->xin[i][0]); dev_free(e->xin[i][1]); dev_free(e->enc_raw[i]);
+        dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
         dev_free(e->enc_stats[i]); dev_free(e->dec_stats[i]); dev_free(e->skip_stats[i]); dev_free(e->enc_g[i]);
         for (ConvPlan *p : {&l.gate[0], &l.gate[1], &l.pre}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); dev_free(p->gatew); }
@@ -910,14 +1013,18 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     if (rc) return rc;
     const int L = e->L, T = e->T, B = batch, H = e->H, D = e->D, F0 = e->F[0];
     e->B = B;
+    for (int i = 0; i < SE_MAX_LEVELS; i++)
+        for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
+            select_conv_geometry(e, *p);
     size_t spec_n = (size_t)B * e->M * T * F0 * 2;
-    if ((rc = dev_alloc(e, e->spec, spec_n)) || (rc = dev_alloc(e, e->maskspec, (size_t)B * T * F0 * 2))) return rc;
+    if ((rc = dev_alloc(e, e->maskspec, (size_t)B * T * F0 * 2))) return rc;
+    for (int r = 0; r < kRing; r++)
+        if ((rc = dev_alloc(e, e->spec[r], spec_n)) || (rc = dev_alloc(e, e->gru_in[r], (size_t)B * T * D)) || (rc = dev_alloc(e, e->dec_in[r], (size_t)B * T * D))) return rc;
     for (int i = 0; i < L; i++) {
         const size_t nin = (size_t)B * e->Ch[i] * T * e->F[i];
-        for (int p = 0; p < 2; p++) {
-            if ((rc = dev_alloc(e, e->xin[i][p], nin))) return rc;
-            HIPCHECK(e, hipMemsetAsync(e->xin[i][p].p, 0, nin * sizeof(float), st));
-        }
+        for (int r = 0; r < kRing; r++)
+            if ((rc = dev_alloc(e, e->xin[i][r], nin))) return rc;
+        HIPCHECK(e, hipMemsetAsync(e->xin[i][0].p, 0, nin * sizeof(float), st));  // slot 0 = the all-zero history of the first segment
         if ((rc = dev_alloc(e, e->enc_raw[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
         if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * (e->lv[i].enc.grid_x + e->lv[i].gate[0].grid_x + e->lv[i].gate[1].grid_x + 1)))) return rc;
         if (e->variant && (rc = dev_alloc(e, e->enc_g[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
@@ -940,9 +1047,9 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
         if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre.grid_x + 1)))) return rc;
         if ((rc = dev_alloc(e, e->pre_g, nf))) return rc;
     }
-    if ((rc = dev_alloc(e, e->gru_in, (size_t)B * T * D)) || (rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
+    if ((rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
         (rc = dev_alloc(e, e->seq[0], (size_t)B * T * H)) || (rc = dev_alloc(e, e->seq[1], (size_t)B * T * H)) ||
-        (rc = dev_alloc(e, e->fc_out, (size_t)B * T * D)) || (rc = dev_alloc(e, e->dec_in, (size_t)B * T * D)))
+        (rc = dev_alloc(e, e->fc_out, (size_t)B * T * D)))
         return rc;
     for (int l = 0; l < e->NL; l++)
         for (int p = 0; p < 2; p++) {
@@ -953,6 +1060,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 128 * sizeof(float), st));
     for (int l = 0; l < 4; l++) e->hcur[l] = 0;
     e->parity = 0;
+    e->slot = 0;
     return SE_OK;
 }
 
@@ -987,10 +1095,27 @@ int se_istft(se_engine *e, const float *spec, int n, float *wav, void *stream) {
     return launch_istft(e, reinterpret_cast<const cf2 *>(spec), F * T, 1, T, n, wav, e->K, static_cast<hipStream_t>(stream));
 }
 
+static int ensure_stage_streams(se_engine *e) {
+    if (e->stage_ready) return 0;
+    int least = 0, greatest = 0;
+    HIPCHECK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int k = 0; k < 3; k++)  // the recurrence is a chain of short dependent launches: its waves go first when a CU frees up
+        HIPCHECK(e, hipStreamCreateWithPriority(&e->stage_stream[k], hipStreamNonBlocking, k == 1 ? greatest : least));
+    for (int r = 0; r < kRing; r++) {
+        HIPCHECK(e, hipEventCreateWithFlags(&e->ev_enc[r], hipEventDisableTiming));
+        HIPCHECK(e, hipEventCreateWithFlags(&e->ev_gru[r], hipEventDisableTiming));
+        HIPCHECK(e, hipEventCreateWithFlags(&e->ev_dec[r], hipEventDisableTiming));
+    }
+    HIPCHECK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIPCHECK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    e->stage_ready = true;
+    return 0;
+}
+
 static int step_dev(se_engine *e, const float *src, long strideB, long strideM, long off, long Lsrc, float *wav_out, long wav_ld, hipStream_t st) {
     const long F = e->F[0], T = e->T, M = e->M;
     int rc;
-    cf2 *spec = reinterpret_cast<cf2 *>(e->spec.p);
+    cf2 *spec = reinterpret_cast<cf2 *>(e->spec[(e->slot + 1) % kRing].p);
     cf2 *ms = reinterpret_cast<cf2 *>(e->maskspec.p);
     if ((rc = launch_stft(e, src, strideB, strideM, (int)M, off, Lsrc, e->B * (int)M, spec, T * F, F, 1, st))) return rc;
     if ((rc = forward_dev(e, spec, M * T * F, T * F, F, 1, ms, T * F, F, 1, st))) return rc;
@@ -1021,11 +1146,57 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
     const long gap = K - (P + Lp % K) % K;               // utility.py:327-329
     const long Nseg = 2 * (Lp + gap + P) / K;            // utility.py:360-368
     if ((rc = dev_alloc(e, e->yseg, (size_t)batch * Nseg * K))) return rc;
-    for (long n = 0; n < Nseg; n++) {
-        // segment n covers padded[n*P, n*P+K) with padded = [0]*P | [0]*lead | x | zeros
-        const long off = n * P - P - lead;
-        // yseg is [B][Nseg][K]: the iSTFT writes segment n of every stream with row stride Nseg*K
-        if ((rc = step_dev(e, mixture, (long)e->M * length, length, off, length, e->yseg.p + n * K, Nseg * K, st))) return rc;
+    const bool piped = e->pipeline && !e->prof_on && Nseg > 1;
+    if (!piped) {
+        for (long n = 0; n < Nseg; n++) {
+            // segment n covers padded[n*P, n*P+K) with padded = [0]*P | [0]*lead | x | zeros
+            const long off = n * P - P - lead;
+            // yseg is [B][Nseg][K]: the iSTFT writes segment n of every stream with row stride Nseg*K
+            if ((rc = step_dev(e, mixture, (long)e->M * length, length, off, length, e->yseg.p + n * K, Nseg * K, st))) return rc;
+        }
+    } else {
+        // Segments are sequentially dependent only WITHIN a stage (conv history, GRU state), so the three stages run as a
+        // software pipeline over segments on three streams: while the bottleneck of segment n walks its 2 x T dependent
+        // GRU launches, the encoder of n+1.. and the decoder of n-1 keep the matrix cores and HBM busy.
+        if ((rc = ensure_stage_streams(e))) return rc;
+        hipStream_t sE = e->stage_stream[0], sG = e->stage_stream[1], sD = e->stage_stream[2];
+        const long F = e->F[0], T = e->T, M = e->M;
+        const size_t spec_n = (size_t)e->B * M * T * F * 2, mask_n = (size_t)e->B * T * F * 2;
+        // The (i)STFT of a chunk of segments runs on the caller's stream before / after the pipelined part: the FFT kernels
+        // are kept out of the concurrent phase (they mis-compute when co-resident with the MFMA kernels).
+        const long CH = std::min<long>(Nseg, kPipeChunk);
+        if ((rc = dev_alloc(e, e->spec_all, spec_n * CH)) || (rc = dev_alloc(e, e->mask_all, mask_n * CH))) return rc;
+        for (long c0 = 0; c0 < Nseg; c0 += CH) {
+            const long cn = std::min(CH, Nseg - c0);
+            for (long i = 0; i < cn; i++) {
+                const long off = (c0 + i) * P - P - lead;
+                if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, off, length, e->B * (int)M,
+                                      reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, st))) return rc;
+            }
+            HIPCHECK(e, hipEventRecord(e->ev_fork, st));
+            for (hipStream_t q : e->stage_stream) HIPCHECK(e, hipStreamWaitEvent(q, e->ev_fork, 0));
+            for (long i = 0; i < cn; i++) {
+                const int prev = e->slot, cur = (prev + 1) % kRing;
+                e->slot = cur;
+                const cf2 *spec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * i);
+                cf2 *ms = reinterpret_cast<cf2 *>(e->mask_all.p + mask_n * i);
+                if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
+                if ((rc = stage_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
+                HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
+                HIPCHECK(e, hipStreamWaitEvent(sG, e->ev_enc[cur], 0));
+                if ((rc = stage_bottleneck(e, cur, sG))) return rc;
+                HIPCHECK(e, hipEventRecord(e->ev_gru[cur], sG));
+                HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[cur], 0));
+                if ((rc = stage_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
+                HIPCHECK(e, hipEventRecord(e->ev_dec[cur], sD));
+            }
+            for (hipStream_t q : e->stage_stream) {  // the last decoder implies every earlier stage, but the join costs nothing
+                HIPCHECK(e, hipEventRecord(e->ev_join, q));
+                HIPCHECK(e, hipStreamWaitEvent(st, e->ev_join, 0));
+            }
+            for (long i = 0; i < cn; i++)
+                if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i), T * F, F, 1, e->B, e->yseg.p + (c0 + i) * K, Nseg * K, st))) return rc;
+        }
     }
     const long skip = lead;  // CRN.py:587-588
     hipLaunchKernelGGL(k_overlap_avg, dim3((unsigned)((length + 255) / 256), batch), dim3(256), 0, st, e->yseg.p, out, (int)Nseg, (int)K,
@@ -1046,16 +1217,16 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
     if (!e || !name || !host_out) return fail(e, SE_ERR_ARG, "null argument");
     if (e->B <= 0) return fail(e, SE_ERR_STATE, "no forward has run");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int L = e->L, T = e->T, B = e->B, cur = e->parity;
+    const int L = e->L, T = e->T, B = e->B, cur = e->slot;
     const float *src = nullptr;
     int C = 0, F = 0, idx = -1;
     bool gru_layout = false;
     if (!strcmp(name, "feat")) { src = e->xin[0][cur].p; C = e->Ch[0]; F = e->F[0]; }
-    else if (!strcmp(name, "gru")) { src = e->dec_in.p; C = e->Ch[L]; F = e->F[L]; }
+    else if (!strcmp(name, "gru")) { src = e->dec_in[cur].p; C = e->Ch[L]; F = e->F[L]; }
     else if (sscanf(name, "enc%d", &idx) == 1 && idx >= 0 && idx < L) {
         C = e->Ch[idx + 1]; F = e->F[idx + 1];
         if (idx + 1 < L) src = e->xin[idx + 1][cur].p;
-        else { src = e->gru_in.p; gru_layout = true; }
+        else { src = e->gru_in[cur].p; gru_layout = true; }
     } else if (sscanf(name, "dec%d", &idx) == 1 && idx >= 0 && idx < L - 1) {
         const int lvl = L - 1 - idx;
         src = e->dec_out[idx].p; C = e->Ch[lvl]; F = e->F[lvl];
@@ -1099,7 +1270,7 @@ int se_export_state(se_engine *e, const char *name, float *host_out, int64_t cap
         if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
         std::vector<float> h(nsrc);
         HIPCHECK(e, hipStreamSynchronize(st));
-        HIPCHECK(e, hipMemcpy(h.data(), (is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->parity]).p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(h.data(), (is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) host_out[(bc * F + f) * P + p] = h[(bc * T + (T - P + p)) * F + f];
@@ -1130,7 +1301,7 @@ int se_import_state(se_engine *e, const char *name, const float *host_in, int64_
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) h[(bc * T + (T - P + p)) * F + f] = host_in[(bc * F + f) * P + p];
-        HIPCHECK(e, hipMemcpy((is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->parity]).p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy((is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
         return SE_OK;
     }
     return fail(e, SE_ERR_KEY, "unknown state %s", name);

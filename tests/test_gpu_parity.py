@@ -200,6 +200,39 @@ def test_full_size_batch256_properties():
     assert rel_rms(y_prefix[:, :8000], y_small[:, :8000]) < 2e-6
 
 
+@pytest.mark.parametrize("batch", [3, 64, 256])
+def test_stage_pipeline_equals_serial(batch, monkeypatch):
+    """se_realtime_process runs the encoder / recurrent / decoder stages of successive segments on three HIP streams
+    (ring of 4 activation slots).  The overlap must not change a single bit: compare with the same
+    engine built with SE_PIPELINE=0 (one stream, stages back to back), twice (slot reuse across calls), and once
+    more with a carried state (flag=True continues from the ring slot the previous call ended on)."""
+    monkeypatch.setenv("SE_PIPELINE", "0")
+    e_serial = _engine(FULL512, seed=5)
+    monkeypatch.setenv("SE_PIPELINE", "1")
+    e_piped = _engine(FULL512, seed=5)
+    mix, _ = synth.synth_utterances(batch, 11200, 3, seed=31)
+    x = _cuda(mix)
+    ref = e_serial.realtime_process(x).cpu().numpy()
+    for _ in range(2):
+        assert np.array_equal(e_piped.realtime_process(x).cpu().numpy(), ref)
+    x2 = _cuda(mix[..., :6400])
+    ref2 = e_serial.realtime_process(x2, flag=True).cpu().numpy()
+    assert np.array_equal(e_piped.realtime_process(x2, flag=True).cpu().numpy(), ref2)
+
+
+def test_stage_pipeline_equals_serial_variants(monkeypatch):
+    """Same bit-exactness for the CRN_ELU (pre-conv chain, gated pairs) and student (hidden 128) pipelines."""
+    for cfg, variant in ((FULL400, 1), (STUDENT400, 2)):
+        monkeypatch.setenv("SE_PIPELINE", "0")
+        e_serial = _engine_v(cfg, variant, seed=6)
+        monkeypatch.setenv("SE_PIPELINE", "1")
+        e_piped = _engine_v(cfg, variant, seed=6)
+        mix, _ = synth.synth_utterances(16, 9600, 3, seed=32)
+        x = _cuda(mix)
+        ref = e_serial.realtime_process(x).cpu().numpy()
+        assert np.array_equal(e_piped.realtime_process(x).cpu().numpy(), ref), variant
+
+
 def test_istft_stft_roundtrip_full_batch():
     """Size-independent property at full batch: iSTFT(STFT(x)) == x on the samples covered by complete frames."""
     e = _engine(dict(FULL512, num_channels=[2, 2, 2, 2], hidden=16))
