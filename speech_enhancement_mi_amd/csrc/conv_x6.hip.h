@@ -5,12 +5,16 @@
 // formed from the six leading cross terms with v_mfma_f32_32x32x16_bf16 (see gemm.hip.h, k_gemm_bf16x6: measured
 // error 2.6e-8 vs 2.6e-7 for a k-ordered fp32 chain).  6 x 32 matrix-pipe cycles per 16-deep K step replace
 // 8 x 64 cycles of v_mfma_f32_32x32x2_f32.
-//   K step  = 2 taps x 8 input channels  (lane half h of the MFMA operand selects the tap, j the channel)
-//   patch   = LDS [plane 3][row][col][8 ch] bf16: one 16-B ds_read_b128 per B fragment at lane_base + tap offset
+//   K step  = 2 (tap, channel-octet) entries x 8 input channels: lane half h of the MFMA operand selects the entry,
+//             j the channel inside the octet.  A chunk stages CO octets (8*CO channels); its NTAP*CO entries are
+//             walked tap-major, so a 1x1 convolution (NTAP = 1) contracts 16 real channels per MFMA instead of
+//             8 channels + 8 zeros, and needs CO times fewer chunk barriers.
+//   patch   = LDS [plane 3][octet CO][row][col][8 ch] bf16: one 16-B ds_read_b128 per B fragment at
+//             lane_base + entry offset
 //   weights = pre-split on the host as [chunk][tap pair][plane][Cout tile][32 co][16 k]: one coalesced 1-KB
 //             global load per A fragment straight to registers (prefetched one pair ahead; no LDS weight slab,
 //             so the LDS holds three patch planes instead)
-//   staging = each thread owns up to 4 patch positions x 8 channels; fp32 values are prefetched into registers
+//   staging = each thread owns up to 4 (position, octet) items x 8 channels; fp32 values are prefetched into registers
 //             during the previous chunk's MFMAs, split and written as three 16-B LDS stores per position.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,11 +23,11 @@
 
 namespace se {
 
-constexpr int kX6PosPerThread = 4;  // patch positions (row, col) per thread: R*St <= 1024 (host-checked)
+constexpr int kX6PosPerThread = 4;  // (patch position, octet) items per thread: CO*R*St <= 1024 (host-checked)
 
 struct ConvX6Args {
     ConvArgs c;        // geometry, x / xprev / bias / y / stats exactly as for k_conv_igemm (c.w unused, c.CC == 8)
-    const uint4 *wx;   // [nchunk][npair][3][MT][64] fragments of 16 B
+    const uint4 *wx;   // [nchunk][nstep][3][MT][64] fragments of 16 B
 #ifdef SE_X6_TRACE
     int trace_slot;
 #endif
@@ -43,11 +47,11 @@ __device__ unsigned long long g_x6_trace[16];
 #define X6T(i)
 #endif
 
-template <int NTAP, int NT>
+template <int NTAP, int NT, int CO>
 __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
-    extern __shared__ __align__(16) uint4 planes[];  // [3][Npos]
+    extern __shared__ __align__(16) uint4 planes[];  // [3][CO][Npos]
     const ConvArgs &a = xa.c;
-    constexpr int NPAIR = (NTAP + 1) / 2;
+    constexpr int NPAIR = (NTAP * CO + 1) / 2;  // K steps per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int P = a.T * a.FP;
@@ -69,11 +73,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
         const int t = pc / a.FP, m = pc - t * a.FP;
         lane_base[i] = (t - ta) * St + a.s * m;
     }
-    int toffL[NPAIR];  // per lane half: position offset of tap 2*pair + half
+    int toffL[NPAIR];  // per lane half: LDS offset of entry 2*step + half = (tap, octet), tap-major
 #pragma unroll
     for (int pr = 0; pr < NPAIR; pr++) {
-        const int tp = min(2 * pr + half, NTAP - 1);  // a padded (zero-weight) tap reads any valid position
-        toffL[pr] = a.rowgrp[tp] * (a.grouped ? RT : a.dil) * St + a.coloff[tp];
+        const int en = min(2 * pr + half, NTAP * CO - 1);  // a padded (zero-weight) entry reads any valid position
+        const int tp = en / CO, oc = en - tp * CO;
+        toffL[pr] = oc * Npos + a.rowgrp[tp] * (a.grouped ? RT : a.dil) * St + a.coloff[tp];
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -85,14 +90,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
     const float *xb = a.x + (long)b * a.Ci * xs_c;
     const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : xb;
 
-    // ---- gather plan over patch positions pe = tid + 256*k ----
+    // ---- gather plan over items it = tid + 256*k = octet * Npos + patch position ----
     int goff[kX6PosPerThread];
-    unsigned okmask = 0, histmask = 0;
+    unsigned okmask = 0, histmask = 0, octs = 0;  // octs: 2 bits per item = its channel octet inside the chunk
     {
         const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
 #pragma unroll
         for (int k = 0; k < kX6PosPerThread; k++) {
-            const int pe = min(tid + 256 * k, Npos - 1);
+            const int item = min(tid + 256 * k, CO * Npos - 1);
+            const int pe = CO > 1 ? item % Npos : item;
             const int r = pe / St, col = pe - r * St;
             const int g = NGp > 1 ? r / RTp : 0, j = r - g * RTp;
             const int ts = ta + a.tlo_off + g * a.dil + j;
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
             const bool ok = fi >= 0 && fi < a.Fi && (hist ? (a.xprev != nullptr && ts + a.T >= 0) : ts < a.T);
             const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1), fic = min(max(fi, 0), a.Fi - 1);
             goff[k] = tsc * a.Fi + fic;
+            octs |= (unsigned)(CO > 1 ? item / Npos : 0) << (2 * k);
             okmask |= (ok ? 1u : 0u) << k;
             histmask |= (hist ? 1u : 0u) << k;
         }
@@ -110,9 +117,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
 #pragma unroll
         for (int k = 0; k < kX6PosPerThread; k++) {
             const float *base = ((histmask >> k) & 1u) ? xpb : xb;
+            const int cbase = ch * 8 * CO + (CO > 1 ? (int)((octs >> (2 * k)) & 3u) * 8 : 0);
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const int ci = min(ch * 8 + c, a.Ci - 1);
+                const int ci = min(cbase + c, a.Ci - 1);
                 pv[k][c] = base[(long)ci * xs_c + goff[k]];  // raw; masked at the LDS write
             }
         }
@@ -134,15 +142,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
 #endif
 #pragma unroll
         for (int k = 0; k < kX6PosPerThread; k++) {
-            const int pe = tid + 256 * k;
-            if (pe < Npos) {
+            const int item = tid + 256 * k;
+            if (item < CO * Npos) {
                 const bool ok = (okmask >> k) & 1u;
+                const int cbase = ch * 8 * CO + (CO > 1 ? (int)((octs >> (2 * k)) & 3u) * 8 : 0);
                 __bf16 h[8], m[8], l[8];
 #pragma unroll
-                for (int c = 0; c < 8; c++) split3((ok && ch * 8 + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
-                planes[pe] = pack_bf16x8(h);
-                planes[Npos + pe] = pack_bf16x8(m);
-                planes[2 * Npos + pe] = pack_bf16x8(l);
+                for (int c = 0; c < 8; c++) split3((ok && cbase + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
+                planes[item] = pack_bf16x8(h);
+                planes[CO * Npos + item] = pack_bf16x8(m);
+                planes[2 * CO * Npos + item] = pack_bf16x8(l);
             }
         }
         X6T(3);
@@ -172,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
             for (int i = 0; i < NT; i++) {
                 const int pos = lane_base[i] + toffL[pr];
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[Npos + pos]);
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * Npos + pos]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[CO * Npos + pos]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
                 f32x16 c = acc[i];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b1, c, 0, 0, 0);  // mid*mid
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b2, c, 0, 0, 0);  // hi*lo

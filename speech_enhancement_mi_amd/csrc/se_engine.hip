@@ -53,6 +53,7 @@ struct ConvPlan {
     DevBuf w, bias;
     bool active = false;
     bool x6 = false;  // bf16x6 kernel (k_conv_x6) instead of the fp32-MFMA k_conv_igemm
+    int CO = 1;       // k_conv_x6: channel octets staged per chunk
     DevBuf wx;
     DevBuf gatew;     // k_conv_small: fused gated 1x1 pair weights
     // k_conv_x6 tilings that fit (index = tiles per wave - 1); the weights do not depend on the tiling, so the one that
@@ -295,40 +296,51 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     if (MT == 3) return fail(e, SE_ERR_ARG, "conv output channels %d need 3 row tiles (unsupported)", Co);
     const int NCG = 4 / MT, NTmax = 4;
     if (e->conv_mode == 6 && (Ci % 8 == 0 || Ci >= 5)) {  // ---- bf16x6 path: K step = 2 taps x 8 channels (Cin zero-padded to 8s) ----
+        // channel octets per chunk: 1x1 convolutions take up to 4 (32 channels) so that both halves of every K step carry
+        // real channels and a chunk holds several K steps; multi-tap convolutions already have NTAP entries per octet
+        int CO = 1;
+        if (ntap == 1) { const int oct = (Ci + 7) / 8; CO = oct >= 4 ? 4 : (oct >= 2 ? 2 : 1); }
+        if (const char *s = getenv("SE_X6_CO")) CO = std::max(1, std::min(CO, atoi(s)));
         int tpw = 0, n_wg = 0, NT = 0, Rmax = 0, grouped = 0;
-        for (int k = 0; k < 4; k++) pl.geo[k] = ConvPlan::Geo{};
-        for (int ntmax = 1; ntmax <= NTmax; ntmax++) {  // ends on the largest tiling that fits = the default geometry
-            const int c_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
-            const int c_tpw = (tiles + c_wg - 1) / c_wg;
-            const int c_NT = (c_tpw + NCG - 1) / NCG;
-            int rows_pos = (c_tpw * 32 + FP - 1) / FP + 1;
-            if (rows_pos > T) rows_pos = T;
-            const int c_grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
-            const int c_Rmax = c_grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
-            if ((size_t)c_Rmax * St > 256 * kX6PosPerThread) continue;
-            ConvPlan::Geo &g = pl.geo[c_NT - 1];
-            g.NT = c_NT; g.tpw = c_tpw; g.n_wg = c_wg; g.grouped = c_grouped;
-            g.lds = std::max<size_t>((size_t)3 * c_Rmax * St * 16, 64);
-            tpw = c_tpw; n_wg = c_wg; NT = c_NT; Rmax = c_Rmax; grouped = c_grouped;
+        for (; CO >= 1; CO >>= 1) {
+            for (int k = 0; k < 4; k++) pl.geo[k] = ConvPlan::Geo{};
+            NT = 0;
+            for (int ntmax = 1; ntmax <= NTmax; ntmax++) {  // ends on the largest tiling that fits = the default geometry
+                const int c_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
+                const int c_tpw = (tiles + c_wg - 1) / c_wg;
+                const int c_NT = (c_tpw + NCG - 1) / NCG;
+                int rows_pos = (c_tpw * 32 + FP - 1) / FP + 1;
+                if (rows_pos > T) rows_pos = T;
+                const int c_grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+                const int c_Rmax = c_grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
+                if ((size_t)CO * c_Rmax * St > 256 * kX6PosPerThread) continue;
+                ConvPlan::Geo &g = pl.geo[c_NT - 1];
+                g.NT = c_NT; g.tpw = c_tpw; g.n_wg = c_wg; g.grouped = c_grouped;
+                g.lds = std::max<size_t>((size_t)3 * CO * c_Rmax * St * 16, 64);
+                tpw = c_tpw; n_wg = c_wg; NT = c_NT; Rmax = c_Rmax; grouped = c_grouped;
+            }
+            if (NT > 0) break;
         }
         if (NT > 0) {
-            const int npair = (ntap + 1) / 2, nchunk = (Ci + 7) / 8;
+            const int nstep = (ntap * CO + 1) / 2, nchunk = (Ci + 8 * CO - 1) / (8 * CO);
             ConvArgs &a = pl.a;
             a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
             a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
-            a.ntap = ntap; a.CC = 8; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+            a.ntap = ntap; a.CC = 8 * CO; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
             a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = gate_pairs; a.Cy = Cy; a.cy0 = cy0;
             for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
-            pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true;
-            pl.lds = std::max<size_t>((size_t)3 * Rmax * St * 16, 64);
-            // weights: [chunk][pair][plane][mtile][co 32][k 16], k = half*8 + c <-> (tap 2*pair+half, channel chunk*8+c)
-            std::vector<uint16_t> wx((size_t)nchunk * npair * 3 * MT * 32 * 16, 0);
+            pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true; pl.CO = CO;
+            pl.lds = std::max<size_t>((size_t)3 * CO * Rmax * St * 16, 64);
+            // weights: [chunk][step][plane][mtile][co 32][k 16], k = half*8 + c <-> entry 2*step+half = (tap, octet) tap-major,
+            // channel chunk*8*CO + octet*8 + c
+            std::vector<uint16_t> wx((size_t)nchunk * nstep * 3 * MT * 32 * 16, 0);
             for (int ch = 0; ch < nchunk; ch++)
-                for (int pr = 0; pr < npair; pr++)
+                for (int st = 0; st < nstep; st++)
                     for (int m = 0; m < MT; m++)
                         for (int r = 0; r < 32; r++)
                             for (int k = 0; k < 16; k++) {
-                                const int tp = 2 * pr + k / 8, ci = ch * 8 + k % 8, co = m * 32 + r;
+                                const int en = 2 * st + k / 8, tp = en / CO, oc = en % CO;
+                                const int ci = (ch * CO + oc) * 8 + k % 8, co = m * 32 + r;
                                 if (tp >= ntap || co >= Co || ci >= Ci) continue;
                                 const float x = wsel(ci, co, taps[tp][0], taps[tp][1]);
                                 const uint16_t h = bf16_rne(x);
@@ -337,7 +349,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
                                 const float r2 = r1 - bf16_to_f32(md);
                                 const uint16_t parts[3] = {h, md, bf16_rne(r2)};
                                 for (int pln = 0; pln < 3; pln++)
-                                    wx[(((((size_t)ch * npair + pr) * 3 + pln) * MT + m) * 32 + r) * 16 + k] = parts[pln];
+                                    wx[(((((size_t)ch * nstep + st) * 3 + pln) * MT + m) * 32 + r) * 16 + k] = parts[pln];
                             }
             int rc = dev_alloc(e, pl.wx, (wx.size() + 1) / 2);
             if (rc) return rc;
@@ -579,12 +591,12 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
 #ifdef SE_X6_TRACE
         { const char *want = getenv("SE_X6_TRACE_LABEL"); xa.trace_slot = (want && label && strcmp(want, label) == 0) ? 0 : -1; }
 #endif
-#define SE_X6_CASE(NTAP_, NT_) \
-    case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_>), grid, dim3(256), pl.lds, st, xa); break;
-#define SE_X6_TAPS(NTAP_) SE_X6_CASE(NTAP_, 1) SE_X6_CASE(NTAP_, 2) SE_X6_CASE(NTAP_, 3) SE_X6_CASE(NTAP_, 4)
-        switch (a.ntap * 8 + pl.NT) {
-            SE_X6_TAPS(15) SE_X6_TAPS(9) SE_X6_TAPS(6) SE_X6_TAPS(1)
-            default: return fail(e, SE_ERR_ARG, "no x6 conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
+#define SE_X6_CASE(NTAP_, NT_, CO_) \
+    case (NTAP_ * 8 + NT_) * 8 + CO_: hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_>), grid, dim3(256), pl.lds, st, xa); break;
+#define SE_X6_TAPS(NTAP_, CO_) SE_X6_CASE(NTAP_, 1, CO_) SE_X6_CASE(NTAP_, 2, CO_) SE_X6_CASE(NTAP_, 3, CO_) SE_X6_CASE(NTAP_, 4, CO_)
+        switch ((a.ntap * 8 + pl.NT) * 8 + pl.CO) {
+            SE_X6_TAPS(15, 1) SE_X6_TAPS(9, 1) SE_X6_TAPS(6, 1) SE_X6_TAPS(1, 1) SE_X6_TAPS(1, 2) SE_X6_TAPS(1, 4)
+            default: return fail(e, SE_ERR_ARG, "no x6 conv kernel instance for %d taps x %d tiles x %d octets", a.ntap, pl.NT, pl.CO);
         }
 #undef SE_X6_TAPS
 #undef SE_X6_CASE
@@ -912,12 +924,12 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
 #undef SE_CONV_ATTR
-#define SE_X6_ATTR(NTAP_)                                                                                                          \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SE_X6_ATTR(15) SE_X6_ATTR(9) SE_X6_ATTR(6) SE_X6_ATTR(1)
+#define SE_X6_ATTR(NTAP_, CO_)                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SE_X6_ATTR(15, 1) SE_X6_ATTR(9, 1) SE_X6_ATTR(6, 1) SE_X6_ATTR(1, 1) SE_X6_ATTR(1, 2) SE_X6_ATTR(1, 4)
 #undef SE_X6_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
