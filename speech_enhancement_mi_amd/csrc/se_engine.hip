@@ -99,6 +99,7 @@ struct se_engine {
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
     int num_cu = 256;         // compute units of the device (MI355X: 256)
+    int conv_small16 = 1;     // SE_CONV_SMALL16=0: first encoder block on k_conv_igemm instead of the vector-ALU kernel
     int conv_geo_fixed = 0;   // SE_CONV_GEO_FIXED=1: always the largest k_conv_x6 tiling (no per-batch selection)
     int conv_mode = 6;        // SE_CONV_MODE: 0 = fp32 MFMA (k_conv_igemm), 6 = bf16x6 where Cin % 8 == 0 (default)
 
@@ -270,8 +271,11 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
     const int T = e->T;
     const int ntap = (int)taps.size();
     const int P = T * FP, tiles = (P + 31) / 32;
-    if (Co <= 8 && !gate_pairs) {  // vector-ALU variant: one thread per position, direct global reads, weights [tap][ci][CW] in LDS
-        const int CW = Co <= 4 ? 4 : 8;
+    // vector-ALU variant: one thread per position, direct global reads, weights [tap][ci][CW] in LDS.  Also taken by the first
+    // encoder block (5 -> 16 channels at full frequency resolution): K = 75 is too shallow for the matrix pipe to matter and
+    // the patch halo of the MFMA kernels costs more than the arithmetic
+    if ((Co <= 8 || (Co <= 16 && Ci <= 8 && e->conv_small16)) && !gate_pairs) {
+        const int CW = Co <= 4 ? 4 : (Co <= 8 ? 8 : 16);
         ConvArgs &a = pl.a;
         a.Ci = Ci; a.Co = Co; a.CoPad = CW; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
         a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = 0;
@@ -607,7 +611,8 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
     case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
 #define SE_CONV_TAPS(NTAP_) SE_CONV_CASE(NTAP_, 1) SE_CONV_CASE(NTAP_, 2) SE_CONV_CASE(NTAP_, 3) SE_CONV_CASE(NTAP_, 4) \
     case NTAP_ * 8: if (a.CoPad == 4) hipLaunchKernelGGL((k_conv_small<NTAP_, 1>), grid, dim3(256), pl.lds, st, a); \
-                    else hipLaunchKernelGGL((k_conv_small<NTAP_, 2>), grid, dim3(256), pl.lds, st, a); break;
+                    else if (a.CoPad == 8) hipLaunchKernelGGL((k_conv_small<NTAP_, 2>), grid, dim3(256), pl.lds, st, a); \
+                    else hipLaunchKernelGGL((k_conv_small<NTAP_, 4>), grid, dim3(256), pl.lds, st, a); break;
     switch (a.ntap * 8 + pl.NT) {
         SE_CONV_TAPS(15) SE_CONV_TAPS(9) SE_CONV_TAPS(6) SE_CONV_TAPS(1)
         case 25 * 8: hipLaunchKernelGGL((k_conv_small<25, 2>), grid, dim3(256), pl.lds, st, a); break;
@@ -892,6 +897,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_CONV_MODE")) e->conv_mode = atoi(s);
     if (const char *s = getenv("SE_CONV_GEO_FIXED")) e->conv_geo_fixed = atoi(s);
     if (const char *s = getenv("SE_PIPELINE")) e->pipeline = atoi(s);
+    if (const char *s = getenv("SE_CONV_SMALL16")) e->conv_small16 = atoi(s);
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) e->num_cu = ncu;
