@@ -83,7 +83,8 @@ struct se_engine {
     std::map<std::string, std::vector<int64_t>> shapes;
     bool weights_ready = false;
     size_t conv_lds_budget = 48 * 1024;
-    bool gru_direct = false;  // SE_GRU_DIRECT=1: always use the register-streaming step kernel
+    int gru_direct = -1;      // SE_GRU_DIRECT: 1 = always k_gru_step (W_hh streamed from L2), 0 = always k_gru_step2 (LDS slice),
+                              // default -1 = k_gru_step in the overlapped (pipelined) bottleneck stage, k_gru_step2 otherwise
     int gru_seq = 0;          // SE_GRU_SEQ=1: one launch per layer (k_gru_seq, in-launch hand-off between steps) instead of one per
                               // time step (k_gru_step2).  Measured SLOWER on MI355X (17 us vs 13.5 us per step at B=256): off by default
     DevBuf gru_sync;          // [0,64) group counters, [64] timeout word of k_gru_seq
@@ -719,7 +720,11 @@ int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, lon
 }
 
 // Stage 2: the recurrent bottleneck (CRN.py:476-481, 256-282)  gru_in[cur] -> dec_in[cur]
-int stage_bottleneck(se_engine *e, int cur, hipStream_t st) {
+// `overlapped`: the stage shares the chip with the encoder / decoder streams.  The GRU step then uses the small-footprint
+// kernel (k_gru_step: 54 VGPRs, 6 KB LDS, W_hh straight from L2) whose waves fit next to two resident convolution
+// workgroups, instead of k_gru_step2 (188 VGPRs, 96 KB LDS slice of W_hh), which is 15 % faster alone but has to wait for
+// a convolution workgroup to retire on every CU at every one of the 2 x T steps (measured: 126k vs 119k frames/s).
+int stage_bottleneck(se_engine *e, int cur, hipStream_t st, bool overlapped = false) {
     const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
     int rc;
     const float *layer_in = e->gru_in[cur].p;
@@ -728,7 +733,7 @@ int stage_bottleneck(se_engine *e, int cur, hipStream_t st) {
         if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
         float *seq = e->seq[l & 1].p;
         const int ngroup = (B + 31) / 32, nhid = (H + 15) / 16;
-        const bool use_seq = e->gru_seq && !e->gru_direct && (H == 512 || H == 128) && nhid <= 256;
+        const bool use_seq = e->gru_seq && e->gru_direct <= 0 && (H == 512 || H == 128) && nhid <= 256;
         if (use_seq) {
             // groups per launch: all workgroups of a launch must be able to become resident (<= 256 CUs, one per CU)
             const int gmax = std::max(1, 256 / nhid);
@@ -751,8 +756,9 @@ int stage_bottleneck(se_engine *e, int cur, hipStream_t st) {
                           e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
             ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
             const dim3 grid((H + 15) / 16, (B + 31) / 32);
-            if (H == 512 && !e->gru_direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
-            else if (H == 128 && !e->gru_direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
+            const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : overlapped;
+            if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
+            else if (H == 128 && !direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
             else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
             e->hcur[l] = hc ^ 1;
         }
@@ -891,7 +897,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     e->plan.npass = fft_plan(cfg->n_fft / 2, e->plan.radices);
     if (!e->plan.npass || e->plan.npass > kMaxRadices) return bail(SE_ERR_ARG, "n_fft must factor into 2s and 5s");
     if (const char *s = getenv("SE_CONV_LDS_KB")) e->conv_lds_budget = (size_t)atoi(s) * 1024;
-    if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0;
+    if (const char *s = getenv("SE_GRU_DIRECT")) e->gru_direct = atoi(s) != 0 ? 1 : 0;
     if (const char *s = getenv("SE_GRU_SEQ")) e->gru_seq = atoi(s);
     if (const char *s = getenv("SE_GEMM_MODE")) e->gemm_mode = atoi(s);
     if (const char *s = getenv("SE_CONV_MODE")) e->conv_mode = atoi(s);
@@ -1202,7 +1208,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 if ((rc = stage_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
                 HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
                 HIPCHECK(e, hipStreamWaitEvent(sG, e->ev_enc[cur], 0));
-                if ((rc = stage_bottleneck(e, cur, sG))) return rc;
+                if ((rc = stage_bottleneck(e, cur, sG, /*overlapped=*/true))) return rc;
                 HIPCHECK(e, hipEventRecord(e->ev_gru[cur], sG));
                 HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[cur], 0));
                 if ((rc = stage_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;

@@ -205,7 +205,10 @@ def test_stage_pipeline_equals_serial(batch, monkeypatch):
     """se_realtime_process runs the encoder / recurrent / decoder stages of successive segments on three HIP streams
     (ring of 4 activation slots).  The overlap must not change a single bit: compare with the same
     engine built with SE_PIPELINE=0 (one stream, stages back to back), twice (slot reuse across calls), and once
-    more with a carried state (flag=True continues from the ring slot the previous call ended on)."""
+    more with a carried state (flag=True continues from the ring slot the previous call ended on).
+    SE_GRU_DIRECT pins the GRU step kernel: by default the overlapped stage uses the small-footprint kernel and the
+    single-stream path the LDS-slice kernel, which differ in summation order (covered by the tolerance test below)."""
+    monkeypatch.setenv("SE_GRU_DIRECT", "1")
     monkeypatch.setenv("SE_PIPELINE", "0")
     e_serial = _engine(FULL512, seed=5)
     monkeypatch.setenv("SE_PIPELINE", "1")
@@ -220,8 +223,20 @@ def test_stage_pipeline_equals_serial(batch, monkeypatch):
     assert np.array_equal(e_piped.realtime_process(x2, flag=True).cpu().numpy(), ref2)
 
 
+def test_stage_pipeline_default_kernels_within_tolerance(monkeypatch):
+    """Default configuration: pipelined (k_gru_step in the overlapped stage) vs single stream (k_gru_step2)."""
+    monkeypatch.setenv("SE_PIPELINE", "0")
+    e_serial = _engine(FULL512, seed=5)
+    monkeypatch.setenv("SE_PIPELINE", "1")
+    e_piped = _engine(FULL512, seed=5)
+    mix, _ = synth.synth_utterances(8, 11200, 3, seed=33)
+    x = _cuda(mix)
+    assert rel_rms(e_piped.realtime_process(x).cpu().numpy(), e_serial.realtime_process(x).cpu().numpy()) < 2e-6
+
+
 def test_stage_pipeline_equals_serial_variants(monkeypatch):
     """Same bit-exactness for the CRN_ELU (pre-conv chain, gated pairs) and student (hidden 128) pipelines."""
+    monkeypatch.setenv("SE_GRU_DIRECT", "0")
     for cfg, variant in ((FULL400, 1), (STUDENT400, 2)):
         monkeypatch.setenv("SE_PIPELINE", "0")
         e_serial = _engine_v(cfg, variant, seed=6)
