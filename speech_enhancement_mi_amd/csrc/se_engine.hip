@@ -817,25 +817,29 @@ int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long s
     return stage_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
 }
 
+// nseg > 1: one launch for nseg consecutive segments (segment y reads off + y*seg_off, writes spec + y*seg_spec)
 int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int M, long off, long Lsrc, int rows,
-                cf2 *spec, long sR, long sT, long sF, hipStream_t st) {
+                cf2 *spec, long sR, long sT, long sF, hipStream_t st, int nseg = 1, long seg_off = 0, long seg_spec = 0) {
     StftArgs a{};
+    a.seg_off = seg_off; a.seg_spec = seg_spec;
     a.src = src; a.strideB = strideB; a.strideM = strideM; a.M = M; a.off = off; a.L = Lsrc;
     a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF;
     a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
     ProfScope ps(e, "k_stft", "stft", 0, st);
-    hipLaunchKernelGGL(k_stft, dim3(rows), dim3(256), stft_lds_bytes(e->K, e->N), st, a);
+    hipLaunchKernelGGL(k_stft, dim3(rows, nseg), dim3(256), stft_lds_bytes(e->K, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
 
-int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int rows, float *wav, long wav_ld, hipStream_t st) {
+int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int rows, float *wav, long wav_ld, hipStream_t st,
+                 int nseg = 1, long seg_spec = 0, long seg_wav = 0) {
     IstftArgs a{};
+    a.seg_spec = seg_spec; a.seg_wav = seg_wav;
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF; a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.wav = wav; a.wav_ld = wav_ld; a.window = e->window.p; a.env = e->env.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
     ProfScope ps(e, "k_istft", "istft", 0, st);
-    hipLaunchKernelGGL(k_istft, dim3(rows), dim3(256), istft_lds_bytes(e->T, e->N), st, a);
+    hipLaunchKernelGGL(k_istft, dim3(rows, nseg), dim3(256), istft_lds_bytes(e->T, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
@@ -1192,11 +1196,8 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         if ((rc = dev_alloc(e, e->spec_all, spec_n * CH)) || (rc = dev_alloc(e, e->mask_all, mask_n * CH))) return rc;
         for (long c0 = 0; c0 < Nseg; c0 += CH) {
             const long cn = std::min(CH, Nseg - c0);
-            for (long i = 0; i < cn; i++) {
-                const long off = (c0 + i) * P - P - lead;
-                if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, off, length, e->B * (int)M,
-                                      reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, st))) return rc;
-            }
+            if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, c0 * P - P - lead, length, e->B * (int)M,
+                                  reinterpret_cast<cf2 *>(e->spec_all.p), T * F, F, 1, st, (int)cn, P, (long)(spec_n / 2)))) return rc;
             HIPCHECK(e, hipEventRecord(e->ev_fork, st));
             for (hipStream_t q : e->stage_stream) HIPCHECK(e, hipStreamWaitEvent(q, e->ev_fork, 0));
             for (long i = 0; i < cn; i++) {
@@ -1218,8 +1219,8 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 HIPCHECK(e, hipEventRecord(e->ev_join, q));
                 HIPCHECK(e, hipStreamWaitEvent(st, e->ev_join, 0));
             }
-            for (long i = 0; i < cn; i++)
-                if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i), T * F, F, 1, e->B, e->yseg.p + (c0 + i) * K, Nseg * K, st))) return rc;
+            if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p), T * F, F, 1, e->B, e->yseg.p + c0 * K, Nseg * K, st,
+                                   (int)cn, (long)(mask_n / 2), K))) return rc;
         }
     }
     const long skip = lead;  // CRN.py:587-588

@@ -53,6 +53,7 @@ struct StftArgs {
     const float *window;    // [N] hamming(win) centred in N
     const cf2 *tw;          // [N] exp(-2 pi i m / N)
     FftPlan plan;
+    long seg_off, seg_spec;  // blockIdx.y = segment of a batch of segments: off += y*seg_off, spec += y*seg_spec
 };
 
 // LDS: sig[K+N] | win[N] | tw[N] (cf2) | bufA[kFftBatch*N/2] | bufB[kFftBatch*N/2]
@@ -70,8 +71,10 @@ __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
     cf2 *bufB = bufA + kFftBatch * N2;
     const int row = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     const float *src = a.src + (long)(row / a.M) * a.strideB + (long)(row % a.M) * a.strideM;
+    const long seg_first = a.off + (long)blockIdx.y * a.seg_off;
+    cf2 *spec_out = a.spec + (long)blockIdx.y * a.seg_spec;
     for (int i = tid; i < K + N; i += nth) {
-        const long k = (long)i - pad + a.off;
+        const long k = (long)i - pad + seg_first;
         sig[i] = (i >= pad && i < pad + K && k >= 0 && k < a.L) ? src[k] : 0.0f;
     }
     for (int i = tid; i < N; i += nth) { win[i] = a.window[i]; tw[i] = a.tw[i]; }
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
         const cf2 *Z = fft_run(bufA, bufB, a.plan, nf, tw);
         for (int i = tid; i < nf * F; i += nth) {
             const int f = i / F, k = i - f * F;
-            a.spec[(long)row * a.sR + (long)(t0 + f) * a.sT + (long)k * a.sF] = rfft_post(Z + f * N2, k, N2, tw);
+            spec_out[(long)row * a.sR + (long)(t0 + f) * a.sT + (long)k * a.sF] = rfft_post(Z + f * N2, k, N2, tw);
         }
         __syncthreads();
     }
@@ -104,6 +107,7 @@ struct IstftArgs {
     const float *env;       // [K] sum_t w^2 at output sample i (already offset by n_fft/2)
     const cf2 *tw;
     FftPlan plan;
+    long seg_spec, seg_wav;  // blockIdx.y = segment of a batch of segments
 };
 
 // LDS: frames[T*N] | win[N] | tw[N] (cf2) | bufA | bufB
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void k_istft(IstftArgs a) {
         const int nf = min(kFftBatch, T - t0);
         for (int i = tid; i < nf * N2; i += nth) {
             const int f = i / N2, k = i - f * N2;
-            const cf2 *s = a.spec + (long)row * a.sR + (long)(t0 + f) * a.sT;
+            const cf2 *s = a.spec + (long)blockIdx.y * a.seg_spec + (long)row * a.sR + (long)(t0 + f) * a.sT;
             cf2 xk = s[(long)k * a.sF], xn = s[(long)(N2 - k) * a.sF];
             if (k == 0) { xk.y = 0; xn.y = 0; }  // C2R ignores Im of DC / Nyquist
             bufA[i] = irfft_pre(xk, xn, k, tw);
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void k_istft(IstftArgs a) {
         if (t1 > T - 1) t1 = T - 1;
         float s = 0.0f;
         for (int t = t0; t <= t1; t++) s += frames[t * N + (pos - t * a.hop)];
-        a.wav[(long)row * a.wav_ld + i] = s / a.env[i];
+        a.wav[(long)blockIdx.y * a.seg_wav + (long)row * a.wav_ld + i] = s / a.env[i];
     }
 }
 
