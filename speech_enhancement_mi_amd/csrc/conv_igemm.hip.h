@@ -19,6 +19,7 @@
 // blocking: one A fragment feeds NT MFMAs).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "norm.hip.h"
 
 namespace se {
 
@@ -58,6 +59,16 @@ struct ConvArgs {
     // follows every block (CRN.py:135-149); nullptr = off.  One slot per workgroup -> deterministic.
     float *stats;
     int stats_nslot, stats_slot0, stats_lo, stats_hi;
+    // Decoder skip gate fused into the 1x1 skip convolution (k_conv_x6 only; CRN.py:387-396).  GEMM rows (2c, 2c+1) hold
+    // residualmask_c and residual_c of the skip tensor; the epilogue writes
+    //     out_c = m * act(residual_c) + (1 - m) * pad(gLN(ydec_c)),   m = sigmoid(gLN(residualmask_c))
+    // where the statistics of residualmask come from a stats-only pass of the same convolution (y == nullptr) and those
+    // of ydec (the transposed convolution of this block) from its epilogue partials.  blend == 0: off.
+    int blend;
+    const float *bl_ydec;                    // [B][Cy][T][bl_Fo]
+    const float *bl_nw, *bl_nb, *bl_mnw, *bl_mnb;  // [Cy] norm / residualnorm affine
+    SlabStats bl_sy, bl_su;
+    int bl_Fo;
 };
 
 // block-wide sum of (s, q) over 256 threads -> one slab slot
@@ -82,12 +93,57 @@ __device__ __forceinline__ float conv_act(float v, int act) {
 // Epilogue shared by k_conv_igemm and k_conv_x6 (both leave 32x32 accumulator tiles: column = position on the lane,
 // rows = GEMM rows in the 16 registers): bias, activation, optional gated-pair product, store [B][Cy][T][Fy], and the
 // per-workgroup partial (sum, sum of squares) for the global layer norm that follows.
+struct BlendStats { float my, iy, mu, iu; };  // mean / 1/std of ydec and of residualmask for this stream
+
 template <int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[NT], const bool (&lane_ok)[NT],
-                                              const int (&pos_t)[NT], const int (&pos_m)[NT], int mt, int half, float *scratch, int b) {
+                                              const int (&pos_t)[NT], const int (&pos_m)[NT], int mt, int half, float *scratch, int b,
+                                              const BlendStats *bs = nullptr) {
     const long ys_c = (long)a.T * a.Fy;
     float *yb = a.y + ((long)b * a.Cy + a.cy0) * ys_c;
     float ssum = 0.0f, ssq = 0.0f;
+    if (a.blend && bs) {  // fused decoder skip gate: 8 (residualmask, residual) row pairs per lane
+        float pb[16], cnw[8], cnb[8], cmw[8], cmb[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int row = mt * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;  // even
+            const int c = min(row >> 1, a.Cy - 1);
+            pb[2 * q] = a.bias[min(row, a.Co - 1)];
+            pb[2 * q + 1] = a.bias[min(row + 1, a.Co - 1)];
+            cnw[q] = a.bl_nw[c]; cnb[q] = a.bl_nb[c]; cmw[q] = a.bl_mnw[c]; cmb[q] = a.bl_mnb[c];
+        }
+        const long yd_c = (long)a.T * a.bl_Fo;
+        const float *ydb = a.bl_ydec + (long)b * a.Cy * yd_c;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            if (!lane_ok[i]) continue;
+            const int f = a.os * pos_m[i] + a.oo;
+            const bool has_y = f < a.bl_Fo;  // the transposed convolution gives 2*Fi - 1 bins: pad with zeros (CRN.py:389-392)
+            const float *ydp = ydb + (long)pos_t[i] * a.bl_Fo + min(f, a.bl_Fo - 1);
+            float yv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {  // all loads of the tile before its first store
+                const int row = mt * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;
+                yv[q] = ydp[(long)min(row >> 1, a.Cy - 1) * yd_c];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) asm volatile("" : "+v"(yv[q]));
+            float *yp = yb + (long)pos_t[i] * a.Fy + f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int row = mt * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;
+                if (row + 1 < a.Co) {
+                    const float u = acc[i][2 * q] + pb[2 * q];
+                    const float v = conv_act(acc[i][2 * q + 1] + pb[2 * q + 1], a.act);
+                    const float yn = has_y ? (yv[q] - bs->my) * bs->iy * cnw[q] + cnb[q] : 0.0f;
+                    const float un = (u - bs->mu) * bs->iu * cmw[q] + cmb[q];
+                    const float m = 1.0f / (1.0f + expf(-un));
+                    yp[(row >> 1) * ys_c] = m * v + (1.0f - m) * yn;
+                }
+            }
+        }
+        return;
+    }
     // the 16 biases of this lane's rows are fetched ONCE, ahead of all stores: a bias load between two stores cannot be
     // hoisted by the compiler (y may alias bias for all it knows) and would cost one L1 round trip per stored element
     float bv[16];
@@ -120,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
                 if (co < a.Co) {
                     float v = acc[i][r] + bv[r];
                     if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
-                    yp[co * ys_c] = v;
+                    if (a.y) yp[co * ys_c] = v;  // y == nullptr: statistics-only pass
                     if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
                 }
             }

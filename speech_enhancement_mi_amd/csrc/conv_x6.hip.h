@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
     constexpr int NPAIR = (NTAP * CO + 1) / 2;  // K steps per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
+    BlendStats bs{0.f, 1.f, 0.f, 1.f};
+    if (NTAP == 1 && a.blend) {  // fused decoder skip gate: this stream's norm statistics (LDS is still free)
+        float *sm = reinterpret_cast<float *>(planes);
+        slab_mean_inv(a.bl_sy, b, sm, bs.my, bs.iy);
+        slab_mean_inv(a.bl_su, b, sm + 2, bs.mu, bs.iu);
+        __syncthreads();
+    }
     const int P = a.T * a.FP;
     const int p0 = blockIdx.x * a.tiles_per_wg * 32;
     if (p0 >= P) return;
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
         }
         ConvArgs a2 = a;
         a2.stats = nullptr;
-        conv_epilogue<NT>(a2, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b);
+        conv_epilogue<NT>(a2, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b, NTAP == 1 ? &bs : nullptr);
         X6T(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         X6T(7);
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
         pos_t[i] = pc / a.FP;
         pos_m[i] = pc - pos_t[i] * a.FP;
     }
-    conv_epilogue<NT>(a, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b);
+    conv_epilogue<NT>(a, acc, lane_ok, pos_t, pos_m, mt, half, reinterpret_cast<float *>(planes), b, NTAP == 1 ? &bs : nullptr);
 #endif
 }
 

@@ -65,6 +65,8 @@ struct ConvPlan {
 struct Level {  // one encoder/decoder level
     ConvPlan enc;
     ConvPlan dec_even, dec_odd, skip;
+    ConvPlan skipm;        // fused skip gate: statistics-only pass of the residualmask convolution
+    bool skip_fused = false;
     ConvPlan gate[2];      // CRN_ELU encoder: conv_trans/conv_gated 1x1 pair, <= 64 output channels per launch
     ConvPlan pre;          // CRN_ELU preconv block i (levels 0..2): 5x5 frequency-dilated conv with the gated pair fused in
     DevBuf enc_nw, enc_nb, dec_nw, dec_nb, dec_mnw, dec_mnb, pre_nw, pre_nb;
@@ -100,6 +102,7 @@ struct se_engine {
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
     int num_cu = 256;         // compute units of the device (MI355X: 256)
+    int skip_fuse = 1;        // SE_SKIP_FUSE=0: skip convolution writes both tensors, k_dec_blend_ew applies the gate
     int conv_small16 = 1;     // SE_CONV_SMALL16=0: first encoder block on k_conv_igemm instead of the vector-ALU kernel
     int conv_geo_fixed = 0;   // SE_CONV_GEO_FIXED=1: always the largest k_conv_x6 tiling (no per-batch selection)
     int conv_mode = 6;        // SE_CONV_MODE: 0 = fp32 MFMA (k_conv_igemm), 6 = bf16x6 where Cin % 8 == 0 (default)
@@ -487,10 +490,32 @@ int prepare_weights(se_engine *e) {
             for (int c = 0; c < Co; c++) { bias2[c] = (*mb)[c]; bias2[Co + c] = (*rb)[c]; }
             std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
             const int Fr = e->F[lvl];
-            rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
-                           [=](int ci, int co, int, int) { return co < Co ? mwp[(size_t)co * Co + ci] : rwp[(size_t)(co - Co) * Co + ci]; },
-                           bias2, Co, 2 * Co, e->act);
-            if (rc) return rc;
+            // Fused form (k_conv_x6 only): rows (2c, 2c+1) = (residualmask_c, residual_c), gate applied in the epilogue, preceded
+            // by a statistics-only pass of the residualmask rows.  Falls back to the two-tensor form + k_dec_blend_ew otherwise.
+            e->lv[j].skip_fused = false;
+            e->lv[j].skipm.active = false;
+            if (e->skip_fuse) {
+                std::vector<float> biasp(2 * Co);
+                for (int c = 0; c < Co; c++) { biasp[2 * c] = (*mb)[c]; biasp[2 * c + 1] = (*rb)[c]; }
+                rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
+                               [=](int ci, int row, int, int) { const int c = row >> 1; return (row & 1) ? rwp[(size_t)c * Co + ci] : mwp[(size_t)c * Co + ci]; },
+                               biasp, 0, 0, e->act, /*gate_pairs=*/0, /*Cy=*/Co, /*cy0=*/0);
+                if (rc) return rc;
+                if (e->lv[j].skip.x6) {
+                    rc = plan_conv(e, e->lv[j].skipm, Co, Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
+                                   [=](int ci, int co, int, int) { return mwp[(size_t)co * Co + ci]; }, *mb, 0, 0, e->act);
+                    if (rc) return rc;
+                    e->lv[j].skip_fused = e->lv[j].skipm.x6;
+                    e->lv[j].skipm.flops = 2.0 * Co * Co * Fr * e->T;
+                }
+            }
+            if (!e->lv[j].skip_fused) {
+                e->lv[j].skipm.active = false;
+                rc = plan_conv(e, e->lv[j].skip, Co, 2 * Co, Fr, Fr, Fr, 1, 1, 0, 0, 0, 1, 0, Fr, t1,
+                               [=](int ci, int co, int, int) { return co < Co ? mwp[(size_t)co * Co + ci] : rwp[(size_t)(co - Co) * Co + ci]; },
+                               bias2, Co, 2 * Co, e->act);
+                if (rc) return rc;
+            }
             e->lv[j].skip.flops = 2.0 * 2 * Co * Co * Fr * e->T;
             if ((rc = dev_upload(e, e->lv[j].dec_mnw, *mnw))) return rc;
             if ((rc = dev_upload(e, e->lv[j].dec_mnb, *mnb))) return rc;
@@ -582,14 +607,26 @@ void select_conv_geometry(se_engine *e, ConvPlan &pl) {
     pl.a.tiles_per_wg = g.tpw; pl.a.grouped = g.grouped;
 }
 
+struct ConvBlend {  // operands of the fused decoder skip gate (ConvArgs::blend)
+    const float *ydec, *nw, *nb, *mnw, *mnb;
+    SlabStats sy, su;
+    int Fo;
+};
+
 int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *xprev, float *y, hipStream_t st, const char *label,
-                float *stats = nullptr, int nslot = 0, int slot0 = 0, int stats_lo = 0, int stats_hi = 0) {
+                float *stats = nullptr, int nslot = 0, int slot0 = 0, int stats_lo = 0, int stats_hi = 0, const ConvBlend *blend = nullptr) {
     if (!pl.active) return 0;
     // algorithmic MACs of this launch as SURVEY.md 8d counts them are attributed by the caller via pl.flops
     ProfScope ps(e, pl.x6 ? "k_conv_x6" : (pl.NT == 0 ? "k_conv_small" : "k_conv_igemm"), label, pl.flops * e->B, st);
     ConvArgs a = pl.a;
     a.x = x; a.xprev = xprev; a.y = y; a.w = pl.w.p; a.bias = pl.bias.p; a.gatew = pl.gatew.p;
     a.stats = stats; a.stats_nslot = nslot; a.stats_slot0 = slot0; a.stats_lo = stats_lo; a.stats_hi = stats_hi;
+    a.blend = 0;
+    if (blend) {
+        if (!pl.x6 || a.ntap != 1) return fail(e, SE_ERR_ARG, "fused skip gate needs the 1x1 k_conv_x6 path");
+        a.blend = 1; a.bl_ydec = blend->ydec; a.bl_nw = blend->nw; a.bl_nb = blend->nb; a.bl_mnw = blend->mnw; a.bl_mnb = blend->mnb;
+        a.bl_sy = blend->sy; a.bl_su = blend->su; a.bl_Fo = blend->Fo;
+    }
     dim3 grid(pl.grid_x, e->B);
     if (pl.x6) {
         ConvX6Args xa{a, reinterpret_cast<const uint4 *>(pl.wx.p)};
@@ -785,16 +822,27 @@ int stage_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long
                               e->dec_stats[j].p, ne + no, ne, 0, Co))) return rc;
         const SlabStats sy{e->dec_stats[j].p, ne + no, (long)Co * T * Fo, e->eps_mode};
         if (lvl > 0) {
-            const int Fr = e->F[lvl], nk = e->lv[j].skip.grid_x;
-            if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str(),
-                                  e->skip_stats[j].p, nk, 0, 0, Co))) return rc;
+            const int Fr = e->F[lvl];
             const long nu = (long)Co * T * Fr;
-            if (nu % 4) return fail(e, SE_ERR_ARG, "decoder tensor size %ld not a multiple of 4", nu);
-            BlendEwArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
-                           e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy, SlabStats{e->skip_stats[j].p, nk, nu, e->eps_mode}, Co, T, Fo, Fr};
-            ProfScope ps(e, "k_dec_blend_ew", "dec_blend", 0, st);
-            hipLaunchKernelGGL(k_dec_blend_ew, dim3((unsigned)((nu / 4 + 1023) / 1024), B), dim3(256), 0, st, bl);
-            HIPCHECK(e, hipGetLastError());
+            if (e->lv[j].skip_fused) {
+                const int nm = e->lv[j].skipm.grid_x;
+                if ((rc = launch_conv(e, e->lv[j].skipm, e->xin[lvl][cur].p, nullptr, nullptr, st, ("skipstat" + std::to_string(j)).c_str(),
+                                      e->skip_stats[j].p, nm, 0, 0, Co))) return rc;
+                ConvBlend bl{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy,
+                             SlabStats{e->skip_stats[j].p, nm, nu, e->eps_mode}, Fo};
+                if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_out[j].p, st, ("skip" + std::to_string(j)).c_str(),
+                                      nullptr, 0, 0, 0, 0, &bl))) return rc;
+            } else {
+                const int nk = e->lv[j].skip.grid_x;
+                if ((rc = launch_conv(e, e->lv[j].skip, e->xin[lvl][cur].p, nullptr, e->dec_uv[j].p, st, ("skip" + std::to_string(j)).c_str(),
+                                      e->skip_stats[j].p, nk, 0, 0, Co))) return rc;
+                if (nu % 4) return fail(e, SE_ERR_ARG, "decoder tensor size %ld not a multiple of 4", nu);
+                BlendEwArgs bl{e->dec_raw[j].p, e->dec_uv[j].p, e->dec_out[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p,
+                               e->lv[j].dec_mnw.p, e->lv[j].dec_mnb.p, sy, SlabStats{e->skip_stats[j].p, nk, nu, e->eps_mode}, Co, T, Fo, Fr};
+                ProfScope ps(e, "k_dec_blend_ew", "dec_blend", 0, st);
+                hipLaunchKernelGGL(k_dec_blend_ew, dim3((unsigned)((nu / 4 + 1023) / 1024), B), dim3(256), 0, st, bl);
+                HIPCHECK(e, hipGetLastError());
+            }
             x = e->dec_out[j].p;
         } else {
             if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
@@ -852,7 +900,7 @@ int ensure_ready(se_engine *e) {
     if (rc) return rc;
     if (replanned && e->B > 0)  // new weights re-made the plans with their default tiling: restore the per-batch choice
         for (int i = 0; i < SE_MAX_LEVELS; i++)
-            for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
+            for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].skipm, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
                 select_conv_geometry(e, *p);
     return 0;
 }
@@ -908,6 +956,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_CONV_GEO_FIXED")) e->conv_geo_fixed = atoi(s);
     if (const char *s = getenv("SE_PIPELINE")) e->pipeline = atoi(s);
     if (const char *s = getenv("SE_CONV_SMALL16")) e->conv_small16 = atoi(s);
+    if (const char *s = getenv("SE_SKIP_FUSE")) e->skip_fuse = atoi(s);
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) e->num_cu = ncu;
@@ -988,7 +1037,7 @@ void se_destroy(se_engine *e) {
     }
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
         Level &l = e->lv[i];
-        for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
+        for (ConvPlan *p : {&l.enc, &l.dec_even, &l.dec_odd, &l.skip, &l.skipm}) { dev_free(p->w); dev_free(p->bias); dev_free(p->wx); }
         for (DevBuf *b : {&l.enc_nw, &l.enc_nb, &l.dec_nw, &l.dec_nb, &l.dec_mnw, &l.dec_mnb}) dev_free(*b);
         dev_free(e->enc_raw[i]);
         dev_free(e->dec_raw[i]); dev_free(e->dec_uv[i]); dev_free(e->dec_out[i]);
@@ -1042,7 +1091,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     const int L = e->L, T = e->T, B = batch, H = e->H, D = e->D, F0 = e->F[0];
     e->B = B;
     for (int i = 0; i < SE_MAX_LEVELS; i++)
-        for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
+        for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].skipm, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
             select_conv_geometry(e, *p);
     size_t spec_n = (size_t)B * e->M * T * F0 * 2;
     if ((rc = dev_alloc(e, e->maskspec, (size_t)B * T * F0 * 2))) return rc;
@@ -1057,7 +1106,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
         if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * (e->lv[i].enc.grid_x + e->lv[i].gate[0].grid_x + e->lv[i].gate[1].grid_x + 1)))) return rc;
         if (e->variant && (rc = dev_alloc(e, e->enc_g[i], (size_t)B * e->Ch[i + 1] * T * e->F[i + 1]))) return rc;
         if ((rc = dev_alloc(e, e->dec_stats[i], (size_t)B * 2 * (e->lv[i].dec_even.grid_x + e->lv[i].dec_odd.grid_x + 1)))) return rc;
-        if ((rc = dev_alloc(e, e->skip_stats[i], (size_t)B * 2 * (e->lv[i].skip.grid_x + 1)))) return rc;
+        if ((rc = dev_alloc(e, e->skip_stats[i], (size_t)B * 2 * (std::max(e->lv[i].skip.grid_x, e->lv[i].skipm.grid_x) + 1)))) return rc;
         const int lvl = L - 1 - i;  // decoder index i
         const int Co = lvl == 0 ? 2 : e->Ch[lvl], Fo = 2 * e->F[lvl + 1] - 1, Fr = e->F[lvl];
         if ((rc = dev_alloc(e, e->dec_raw[i], (size_t)B * Co * T * Fo))) return rc;
