@@ -71,7 +71,7 @@ def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950 it reports half
     of a wide coalesced read).  Only valid for the default workload; None otherwise or if the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_bench_b256_nfft512_pmc_hbm.csv")
+    path = os.path.join(ROOT, "profiles", "r01_v4_bench_b256_nfft512_pmc_hbm.csv")
     if not os.path.exists(path) or args.batch != 256 or args.nfft != 512 or args.model != "crn":
         return None
     import csv
