@@ -506,7 +506,7 @@ int prepare_weights(se_engine *e) {
                                    [=](int ci, int co, int, int) { return mwp[(size_t)co * Co + ci]; }, *mb, 0, 0, e->act);
                     if (rc) return rc;
                     e->lv[j].skip_fused = e->lv[j].skipm.x6;
-                    e->lv[j].skipm.flops = 2.0 * Co * Co * Fr * e->T;
+                    e->lv[j].skipm.flops = 0;  // recomputation, not algorithmic work (SURVEY 8d accounting counts the skip GEMM once)
                 }
             }
             if (!e->lv[j].skip_fused) {
