@@ -1158,10 +1158,89 @@ int se_forward(se_engine *e, const float *x, float *y, void *stream) {
                        static_cast<hipStream_t>(stream));
 }
 
+#ifdef SE_DBG_STFT
+// k_stft with self-checks (co-execution study): counters[0] = sig words changed during the kernel, [1] = window/twiddle
+// words changed, [2] = output values that differ when the FFT of the same round is recomputed, [3] = rounds checked
+__device__ unsigned long long g_stft_dbg[8];
+__global__ __launch_bounds__(256) void k_stft_dbg(StftArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.plan.N, N2 = N / 2, K = a.K, T = a.T, F = a.F, pad = N / 2;
+    float *sig = reinterpret_cast<float *>(smem);
+    float *win = sig + K + N;
+    cf2 *tw = reinterpret_cast<cf2 *>(win + N);
+    cf2 *bufA = tw + N;
+    cf2 *bufB = bufA + kFftBatch * N2;
+    const int row = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const float *src = a.src + (long)(row / a.M) * a.strideB + (long)(row % a.M) * a.strideM;
+    for (int i = tid; i < K + N; i += nth) {
+        const long k = (long)i - pad + a.off;
+        sig[i] = (i >= pad && i < pad + K && k >= 0 && k < a.L) ? src[k] : 0.0f;
+    }
+    for (int i = tid; i < N; i += nth) { win[i] = a.window[i]; tw[i] = a.tw[i]; }
+    __syncthreads();
+    unsigned bad_out = 0;
+    for (int t0 = 0; t0 < T; t0 += kFftBatch) {
+        const int nf = min(kFftBatch, T - t0);
+        cf2 first[12];  // this thread's outputs of the first computation (nf*F / 256 <= 12)
+        for (int rep = 0; rep < 2; rep++) {
+            for (int i = tid; i < nf * N2; i += nth) {
+                const int f = i / N2, n = i - f * N2;
+                const float *sp = sig + (t0 + f) * a.hop + 2 * n;
+                bufA[i] = cf2{win[2 * n] * sp[0], win[2 * n + 1] * sp[1]};
+            }
+            __syncthreads();
+            const cf2 *Z = fft_run(bufA, bufB, a.plan, nf, tw);
+            int q = 0;
+            for (int i = tid; i < nf * F; i += nth, q++) {
+                const int f = i / F, k = i - f * F;
+                const cf2 v = rfft_post(Z + f * N2, k, N2, tw);
+                if (rep == 0) {
+                    if (q < 12) first[q] = v;
+                    a.spec[(long)row * a.sR + (long)(t0 + f) * a.sT + (long)k * a.sF] = v;
+                } else if (q < 12) {
+                    bad_out += (v.x != first[q].x) || (v.y != first[q].y);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned bad_sig = 0, bad_tab = 0;
+    for (int i = tid; i < K + N; i += nth) {
+        const long k = (long)i - pad + a.off;
+        const float want = (i >= pad && i < pad + K && k >= 0 && k < a.L) ? src[k] : 0.0f;
+        bad_sig += sig[i] != want;
+    }
+    for (int i = tid; i < N; i += nth) bad_tab += (win[i] != a.window[i]) || (tw[i].x != a.tw[i].x) || (tw[i].y != a.tw[i].y);
+    if (bad_sig) atomicAdd(&g_stft_dbg[0], (unsigned long long)bad_sig);
+    if (bad_tab) atomicAdd(&g_stft_dbg[1], (unsigned long long)bad_tab);
+    if (bad_out) atomicAdd(&g_stft_dbg[2], (unsigned long long)bad_out);
+    if (tid == 0) atomicAdd(&g_stft_dbg[3], 1ull);
+}
+#endif
+
 int se_stft(se_engine *e, const float *seg, int n, float *spec, void *stream) {
     if (!e || !seg || !spec || n <= 0) return fail(e, SE_ERR_ARG, "bad argument");
     HIPCHECK(e, hipSetDevice(e->device));
     const long F = e->F[0], T = e->T;
+#ifdef SE_DBG_STFT
+    if (getenv("SE_DBG_STFT_RUN")) {
+        StftArgs a{};
+        a.src = seg; a.strideB = e->K; a.strideM = 0; a.M = 1; a.off = 0; a.L = e->K;
+        a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
+        a.spec = reinterpret_cast<cf2 *>(spec); a.sR = F * T; a.sT = 1; a.sF = T;
+        a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes(e->K, e->N));
+        hipLaunchKernelGGL(k_stft_dbg, dim3(n), dim3(256), stft_lds_bytes(e->K, e->N), static_cast<hipStream_t>(stream), a);
+        static int calls = 0;
+        if (++calls % 1000 == 0 || getenv("SE_DBG_STFT_PRINT")) {
+            (void)hipDeviceSynchronize();
+            unsigned long long t[8];
+            (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stft_dbg), sizeof(t));
+            fprintf(stderr, "[stft dbg] after %d calls: sig words changed %llu, table words changed %llu, recomputed outputs differing %llu, workgroups %llu\n", calls, t[0], t[1], t[2], t[3]);
+        }
+        return SE_OK;
+    }
+#endif
     return launch_stft(e, seg, e->K, 0, 1, 0, e->K, n, reinterpret_cast<cf2 *>(spec), F * T, 1, T, static_cast<hipStream_t>(stream));
 }
 
