@@ -174,7 +174,7 @@ int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, lo
     FHIP(e, hipGetLastError());
     {
         FsnMaskArgs a{e->mask.p, spec_out ? re : nullptr, spec_out ? im : nullptr, sB, sT, sF, spec_out, oB, oT, oF, crm_out, T, F};
-        hipLaunchKernelGGL(k_fsn_mask, dim3((T * F + 255) / 256, B), dim3(256), 0, st, a);
+        launch_k_fsn_mask(dim3((T * F + 255) / 256, B), st, a);
         FHIP(e, hipGetLastError());
     }
     return 0;
@@ -325,7 +325,7 @@ int fsn_realtime_process(fsn_engine *e, const float *mixture, int batch, int64_t
         if ((rc = fsn_forward_dev(e, sp, sp + 1, 2 * M * T * F, 2 * T * F, 2 * F, 2, nullptr, ms, T * F, F, 1, st))) return rc;
         if (launch_istft(e->sig, ms, T * F, F, 1, batch, e->yseg.p + n * K, Nseg * K, st)) return ffail(e, SE_ERR_HIP, "istft: %s", se_last_error(e->sig));
     }
-    hipLaunchKernelGGL(k_overlap_avg, dim3((unsigned)((length + 255) / 256), batch), dim3(256), 0, st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, lead);
+    launch_k_overlap_avg(dim3((unsigned)((length + 255) / 256), batch), st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, lead);
     FHIP(e, hipGetLastError());
     return SE_OK;
 }

@@ -63,6 +63,7 @@ struct FeatArgs {
     int atan2_phase;  // 0: arctan(im/(re+eps)+eps) (CRN.py:464, distillation_crn.py:340); 1: atan2(im, re) (CRN_ELU.py:370)
 };
 
+#ifndef SE_AUX_KERNELS
 __global__ void k_featurize(FeatArgs a) {
     const int b = blockIdx.y;
     const int TF = a.T * a.F;
@@ -81,6 +82,8 @@ __global__ void k_featurize(FeatArgs a) {
     }
 }
 
+#endif  // !SE_AUX_KERNELS
+
 // ---- gLN with optional re-layout ---------------------------------------------------------------
 struct GlnArgs {
     const float *x;  // per stream n contiguous floats
@@ -93,6 +96,7 @@ struct GlnArgs {
     int eps_mode;
 };
 
+#ifndef SE_AUX_KERNELS
 __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
     __shared__ double red[16];
     const float *x = a.x + (long)blockIdx.x * a.n;
@@ -118,6 +122,8 @@ __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
         }
     }
 }
+
+#endif  // !SE_AUX_KERNELS
 
 // ---- cIRM decompression (utility.py:439-442) --------------------------------------------------------------
 __device__ inline float decompress_cirm(float m) {
@@ -161,6 +167,7 @@ struct GlnEwArgs {
 
 // VW = 4: float4 path (n % 4 == 0, so every stream's base stays 16-B aligned); VW = 1: scalar path for odd sizes
 // (the 5-channel preconv tensors of CRN_ELU: 5*21*201 elements).
+#ifndef SE_AUX_KERNELS
 template <int VW>
 __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     __shared__ float sm[2];
@@ -209,6 +216,8 @@ __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     }
 }
 
+#endif  // !SE_AUX_KERNELS
+
 struct BlendEwArgs {
     const float *y, *uv;
     float *out;
@@ -217,6 +226,7 @@ struct BlendEwArgs {
     int Co, T, Fo, Fr;
 };
 
+#ifndef SE_AUX_KERNELS
 __global__ __launch_bounds__(256) void k_dec_blend_ew(BlendEwArgs a) {
     __shared__ float sm[4];
     const int b = blockIdx.y;
@@ -250,6 +260,8 @@ __global__ __launch_bounds__(256) void k_dec_blend_ew(BlendEwArgs a) {
     }
 }
 
+#endif  // !SE_AUX_KERNELS
+
 struct MaskEwArgs {
     const float *y;
     const float *nw, *nb;
@@ -261,6 +273,9 @@ struct MaskEwArgs {
     int T, F;
 };
 
+void launch_k_final_mask_ew(dim3 grid, hipStream_t st, const MaskEwArgs &a);  // defined in se_aux.hip
+
+#ifdef SE_AUX_KERNELS
 __global__ __launch_bounds__(256) void k_final_mask_ew(MaskEwArgs a) {
     __shared__ float sm[2];
     const int b = blockIdx.y;
@@ -276,5 +291,7 @@ __global__ __launch_bounds__(256) void k_final_mask_ew(MaskEwArgs a) {
         a.out[(long)b * a.oB + (long)t * a.oT + (long)f * a.oF] = cf2{mr * n.x - mi * n.y, mi * n.x + mr * n.y};
     }
 }
+
+#endif  // SE_AUX_KERNELS
 
 }  // namespace se

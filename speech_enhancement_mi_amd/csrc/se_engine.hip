@@ -848,7 +848,7 @@ int stage_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long
             if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
             MaskEwArgs m{e->dec_raw[j].p, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, sy, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
             ProfScope ps(e, "k_final_mask_ew", "final_mask", 0, st);
-            hipLaunchKernelGGL(k_final_mask_ew, dim3((T * e->F[0] + 1023) / 1024, B), dim3(256), 0, st, m);
+            launch_k_final_mask_ew(dim3((T * e->F[0] + 1023) / 1024, B), st, m);
             HIPCHECK(e, hipGetLastError());
         }
     }
@@ -875,7 +875,7 @@ int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int 
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF;
     a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
     ProfScope ps(e, "k_stft", "stft", 0, st);
-    hipLaunchKernelGGL(k_stft, dim3(rows, nseg), dim3(256), stft_lds_bytes(e->K, e->N), st, a);
+    launch_k_stft(dim3(rows, nseg), stft_lds_bytes(e->K, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
@@ -887,7 +887,7 @@ int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int r
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF; a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.wav = wav; a.wav_ld = wav_ld; a.window = e->window.p; a.env = e->env.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
     ProfScope ps(e, "k_istft", "istft", 0, st);
-    hipLaunchKernelGGL(k_istft, dim3(rows, nseg), dim3(256), istft_lds_bytes(e->T, e->N), st, a);
+    launch_k_istft(dim3(rows, nseg), istft_lds_bytes(e->T, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
@@ -979,8 +979,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
         g_create_error = e->err; delete e; return rc;
     }
     // opt in to large dynamic LDS for the FFT kernels
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes(K, N));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)istft_lds_bytes(T, N));
+    aux_set_fft_lds((int)stft_lds_bytes(K, N), (int)istft_lds_bytes(T, N));
 #define SE_CONV_ATTR(NTAP_)                                                                                                        \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1162,6 +1161,44 @@ int se_forward(se_engine *e, const float *x, float *y, void *stream) {
 // k_stft with self-checks (co-execution study): counters[0] = sig words changed during the kernel, [1] = window/twiddle
 // words changed, [2] = output values that differ when the FFT of the same round is recomputed, [3] = rounds checked
 __device__ unsigned long long g_stft_dbg[8];
+// redundant-execution checks: the same FP32 chain twice in registers (VALU), and the same LDS butterfly pass twice
+__global__ __launch_bounds__(256) void k_dbg_redundant(int iters) {
+    extern __shared__ __align__(16) float lv[];
+    const int tid = threadIdx.x;
+    unsigned bad_valu = 0, bad_lds = 0;
+    for (int it = 0; it < iters; it++) {
+        float a0 = 1.0f + tid * 1e-3f + it, b0 = 0.5f + tid * 1e-4f;
+        float a1 = a0, b1 = b0;
+        asm volatile("" : "+v"(a1), "+v"(b1));
+        float x0 = a0, x1 = a1, y0 = b0, y1 = b1;
+#pragma unroll 16
+        for (int k = 0; k < 128; k++) {
+            x0 = fmaf(x0, 0.999f, y0); y0 = fmaf(y0, 1.001f, -x0 * 1e-3f);
+            x1 = fmaf(x1, 0.999f, y1); y1 = fmaf(y1, 1.001f, -x1 * 1e-3f);
+            asm volatile("" : "+v"(x1), "+v"(y1));
+        }
+        bad_valu += (x0 != x1) || (y0 != y1);
+        // LDS: write per-thread values, barrier, read a permuted neighbour's, combine, twice into two buffers, compare
+        float *A = lv, *B = lv + 4096, *C = lv + 8192;
+        for (int i = tid; i < 4096; i += 256) A[i] = x0 + i;
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256) {
+            const int j = (i * 5 + 1) & 4095, k2 = (i * 13 + 7) & 4095;
+            B[i] = A[j] * 1.25f + A[k2];
+        }
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256) {
+            const int j = (i * 5 + 1) & 4095, k2 = (i * 13 + 7) & 4095;
+            C[i] = A[j] * 1.25f + A[k2];
+        }
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256) bad_lds += B[i] != C[i];
+        __syncthreads();
+    }
+    if (bad_valu) atomicAdd(&g_stft_dbg[4], (unsigned long long)bad_valu);
+    if (bad_lds) atomicAdd(&g_stft_dbg[5], (unsigned long long)bad_lds);
+    if (tid == 0) atomicAdd(&g_stft_dbg[6], 1ull);
+}
 __global__ __launch_bounds__(256) void k_stft_dbg(StftArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.plan.N, N2 = N / 2, K = a.K, T = a.T, F = a.F, pad = N / 2;
@@ -1178,9 +1215,34 @@ __global__ __launch_bounds__(256) void k_stft_dbg(StftArgs a) {
     }
     for (int i = tid; i < N; i += nth) { win[i] = a.window[i]; tw[i] = a.tw[i]; }
     __syncthreads();
-    unsigned bad_out = 0;
+    unsigned bad_out = 0, bad_fill = 0, bad_p1 = 0;
+    cf2 *bufC = bufB + kFftBatch * N2;  // third buffer for the redundant fill / first pass (launch adds its bytes)
     for (int t0 = 0; t0 < T; t0 += kFftBatch) {
         const int nf = min(kFftBatch, T - t0);
+        // redundant fill: A and C from the same sig / win
+        for (int i = tid; i < nf * N2; i += nth) {
+            const int f = i / N2, n = i - f * N2;
+            const float *sp = sig + (t0 + f) * a.hop + 2 * n;
+            bufA[i] = cf2{win[2 * n] * sp[0], win[2 * n + 1] * sp[1]};
+        }
+        for (int i = tid; i < nf * N2; i += nth) {
+            const int f = i / N2, n = i - f * N2;
+            const float *sp = sig + (t0 + f) * a.hop + 2 * n;
+            bufC[i] = cf2{win[2 * n] * sp[0], win[2 * n + 1] * sp[1]};
+        }
+        __syncthreads();
+        for (int i = tid; i < nf * N2; i += nth) bad_fill += (bufA[i].x != bufC[i].x) || (bufA[i].y != bufC[i].y);
+        __syncthreads();
+        // redundant first pass: A -> B and A -> C
+        const int R0 = a.plan.radices[0];
+        if (R0 == 4) {
+            fft_pass<4>(bufA, bufB, N2, N2, nf, 1, tw, tid, nth, 2);
+            __syncthreads();
+            fft_pass<4>(bufA, bufC, N2, N2, nf, 1, tw, tid, nth, 2);
+            __syncthreads();
+            for (int i = tid; i < nf * N2; i += nth) bad_p1 += (bufB[i].x != bufC[i].x) || (bufB[i].y != bufC[i].y);
+            __syncthreads();
+        }
         cf2 first[12];  // this thread's outputs of the first computation (nf*F / 256 <= 12)
         for (int rep = 0; rep < 2; rep++) {
             for (int i = tid; i < nf * N2; i += nth) {
@@ -1204,6 +1266,8 @@ __global__ __launch_bounds__(256) void k_stft_dbg(StftArgs a) {
             __syncthreads();
         }
     }
+    if (bad_fill) atomicAdd(&g_stft_dbg[4], (unsigned long long)bad_fill);
+    if (bad_p1) atomicAdd(&g_stft_dbg[5], (unsigned long long)bad_p1);
     unsigned bad_sig = 0, bad_tab = 0;
     for (int i = tid; i < K + N; i += nth) {
         const long k = (long)i - pad + a.off;
@@ -1223,20 +1287,31 @@ int se_stft(se_engine *e, const float *seg, int n, float *spec, void *stream) {
     HIPCHECK(e, hipSetDevice(e->device));
     const long F = e->F[0], T = e->T;
 #ifdef SE_DBG_STFT
+    if (getenv("SE_DBG_REDUNDANT")) {
+        hipLaunchKernelGGL(k_dbg_redundant, dim3(n), dim3(256), 3 * 4096 * 4, static_cast<hipStream_t>(stream), 20);
+        static int calls2 = 0;
+        if (++calls2 % 1000 == 0) {
+            (void)hipDeviceSynchronize();
+            unsigned long long t[8];
+            (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stft_dbg), sizeof(t));
+            fprintf(stderr, "[redundant dbg] after %d calls: VALU chain mismatches %llu, LDS pass mismatches %llu, workgroups %llu\n", calls2, t[4], t[5], t[6]);
+        }
+        return SE_OK;
+    }
     if (getenv("SE_DBG_STFT_RUN")) {
         StftArgs a{};
         a.src = seg; a.strideB = e->K; a.strideM = 0; a.M = 1; a.off = 0; a.L = e->K;
         a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
         a.spec = reinterpret_cast<cf2 *>(spec); a.sR = F * T; a.sT = 1; a.sF = T;
         a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes(e->K, e->N));
-        hipLaunchKernelGGL(k_stft_dbg, dim3(n), dim3(256), stft_lds_bytes(e->K, e->N), static_cast<hipStream_t>(stream), a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stft_lds_bytes(e->K, e->N) + sizeof(cf2) * kFftBatch * (e->N / 2)));
+        hipLaunchKernelGGL(k_stft_dbg, dim3(n), dim3(256), stft_lds_bytes(e->K, e->N) + sizeof(cf2) * kFftBatch * (e->N / 2), static_cast<hipStream_t>(stream), a);
         static int calls = 0;
         if (++calls % 1000 == 0 || getenv("SE_DBG_STFT_PRINT")) {
             (void)hipDeviceSynchronize();
             unsigned long long t[8];
             (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stft_dbg), sizeof(t));
-            fprintf(stderr, "[stft dbg] after %d calls: sig words changed %llu, table words changed %llu, recomputed outputs differing %llu, workgroups %llu\n", calls, t[0], t[1], t[2], t[3]);
+            fprintf(stderr, "[stft dbg] after %d calls: sig words changed %llu, table words changed %llu, recomputed outputs differing %llu, workgroups %llu, redundant fill mismatches %llu, redundant first-pass mismatches %llu\n", calls, t[0], t[1], t[2], t[3], t[4], t[5]);
         }
         return SE_OK;
     }
@@ -1352,8 +1427,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         }
     }
     const long skip = lead;  // CRN.py:587-588
-    hipLaunchKernelGGL(k_overlap_avg, dim3((unsigned)((length + 255) / 256), batch), dim3(256), 0, st, e->yseg.p, out, (int)Nseg, (int)K,
-                       (long)length, skip);
+    launch_k_overlap_avg(dim3((unsigned)((length + 255) / 256), batch), st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, skip);
     HIPCHECK(e, hipGetLastError());
     return SE_OK;
 }

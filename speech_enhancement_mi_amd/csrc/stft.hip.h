@@ -61,6 +61,7 @@ inline size_t stft_lds_bytes(int K, int N) {
     return sizeof(float) * (size_t)(K + N + N) + sizeof(cf2) * (size_t)(N + kFftBatch * N);
 }
 
+#ifdef SE_AUX_KERNELS  // kernel bodies live in se_aux.hip (compiled without SLP vectorisation, see its header)
 __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.plan.N, N2 = N / 2, K = a.K, T = a.T, F = a.F, pad = N / 2;
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
     }
 }
 
+#endif  // SE_AUX_KERNELS
+
 struct IstftArgs {
     const cf2 *spec;        // element (row, t, f) at spec[row*sR + t*sT + f*sF]
     long sR, sT, sF;
@@ -115,6 +118,7 @@ inline size_t istft_lds_bytes(int T, int N) {
     return sizeof(float) * (size_t)(T * N + N) + sizeof(cf2) * (size_t)(N + kFftBatch * N);
 }
 
+#ifdef SE_AUX_KERNELS
 __global__ __launch_bounds__(256) void k_istft(IstftArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.plan.N, N2 = N / 2, K = a.K, T = a.T, pad = N / 2;
@@ -172,5 +176,13 @@ __global__ void k_overlap_avg(const float *yseg, float *out, int Nseg, int K, lo
     const float v2 = y[(2 * (i2 / K) + 1) * K + i2 % K];
     out[(long)b * L + i] = (v1 + v2) / 2;
 }
+
+#endif  // SE_AUX_KERNELS
+
+// host-side launchers, defined in se_aux.hip
+void launch_k_stft(dim3 grid, size_t lds, hipStream_t st, const StftArgs &a);
+void launch_k_istft(dim3 grid, size_t lds, hipStream_t st, const IstftArgs &a);
+void launch_k_overlap_avg(dim3 grid, hipStream_t st, const float *yseg, float *out, int Nseg, int K, long L, long skip);
+void aux_set_fft_lds(int stft_bytes, int istft_bytes);
 
 }  // namespace se

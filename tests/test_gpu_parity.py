@@ -248,6 +248,32 @@ def test_stage_pipeline_equals_serial_variants(monkeypatch):
         assert np.array_equal(e_piped.realtime_process(x).cpu().numpy(), ref), variant
 
 
+def test_fft_kernels_exact_under_coexecution(monkeypatch):
+    """Regression test for the packed-FP32 co-residency fault (csrc/se_aux.hip): the STFT / iSTFT of one
+    engine must stay bit-exact while an unrelated engine runs its MFMA kernels on another stream.  Before the FFT
+    kernels were built without packed-FP32 instructions 30-40 % of these launches returned wrong frames."""
+    monkeypatch.setenv("SE_PIPELINE", "0")
+    e_a, e_b = _engine(FULL512, seed=1), _engine(FULL512, seed=2)
+    mix, _ = synth.synth_utterances(64, 16000, 3, seed=3)
+    x = _cuda(mix)
+    seg = torch.randn(96, 3200, device="cuda")
+    ref = e_b.stft(seg).clone()
+    ref_i = e_b.istft(ref).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(3):  # iteration 0 allocates (which serialises the streams); 1 and 2 overlap for real
+        outs, outs_i = [], []
+        with torch.cuda.stream(s1):
+            e_a.realtime_process(x)
+        with torch.cuda.stream(s2):
+            for _ in range(60):
+                outs.append(e_b.stft(seg))
+                outs_i.append(e_b.istft(ref))
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs), it
+        assert all(torch.equal(o, ref_i) for o in outs_i), it
+
+
 def test_istft_stft_roundtrip_full_batch():
     """Size-independent property at full batch: iSTFT(STFT(x)) == x on the samples covered by complete frames."""
     e = _engine(dict(FULL512, num_channels=[2, 2, 2, 2], hidden=16))
