@@ -42,6 +42,7 @@ struct DevBuf {
     size_t n = 0;
 };
 
+constexpr int kFftSub = 8;      // segments per STFT / iSTFT launch inside the pipelined path
 constexpr int kPipeChunk = 64;  // segments per pipelined chunk (bounds spec_all / mask_all)
 constexpr int kRing = 4;  // stage-crossing activation slots (see se_engine::slot)
 
@@ -1393,14 +1394,13 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         hipStream_t sE = e->stage_stream[0], sG = e->stage_stream[1], sD = e->stage_stream[2];
         const long F = e->F[0], T = e->T, M = e->M;
         const size_t spec_n = (size_t)e->B * M * T * F * 2, mask_n = (size_t)e->B * T * F * 2;
-        // The (i)STFT of a chunk of segments runs on the caller's stream before / after the pipelined part: the FFT kernels
-        // are kept out of the concurrent phase (they mis-compute when co-resident with the MFMA kernels).
+        // The STFT of kFftSub segments is one launch on the encoder stream ahead of their encoders, the iSTFT one launch on
+        // the decoder stream behind their decoders: both overlap with the other stages of neighbouring segments.  (The FFT
+        // kernels are safe next to the MFMA kernels since they are built without packed-FP32 instructions, se_aux.hip.)
         const long CH = std::min<long>(Nseg, kPipeChunk);
         if ((rc = dev_alloc(e, e->spec_all, spec_n * CH)) || (rc = dev_alloc(e, e->mask_all, mask_n * CH))) return rc;
         for (long c0 = 0; c0 < Nseg; c0 += CH) {
             const long cn = std::min(CH, Nseg - c0);
-            if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, c0 * P - P - lead, length, e->B * (int)M,
-                                  reinterpret_cast<cf2 *>(e->spec_all.p), T * F, F, 1, st, (int)cn, P, (long)(spec_n / 2)))) return rc;
             HIPCHECK(e, hipEventRecord(e->ev_fork, st));
             for (hipStream_t q : e->stage_stream) HIPCHECK(e, hipStreamWaitEvent(q, e->ev_fork, 0));
             for (long i = 0; i < cn; i++) {
@@ -1408,6 +1408,11 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 e->slot = cur;
                 const cf2 *spec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * i);
                 cf2 *ms = reinterpret_cast<cf2 *>(e->mask_all.p + mask_n * i);
+                if (i % kFftSub == 0) {
+                    const long ns = std::min<long>(kFftSub, cn - i);
+                    if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, (c0 + i) * P - P - lead, length, e->B * (int)M,
+                                          reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, sE, (int)ns, P, (long)(spec_n / 2)))) return rc;
+                }
                 if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
                 if ((rc = stage_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
                 HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
@@ -1416,14 +1421,17 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 HIPCHECK(e, hipEventRecord(e->ev_gru[cur], sG));
                 HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[cur], 0));
                 if ((rc = stage_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
+                if (i % kFftSub == kFftSub - 1 || i == cn - 1) {
+                    const long i0 = i - i % kFftSub;
+                    if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i0), T * F, F, 1, e->B,
+                                           e->yseg.p + (c0 + i0) * K, Nseg * K, sD, (int)(i - i0 + 1), (long)(mask_n / 2), K))) return rc;
+                }
                 HIPCHECK(e, hipEventRecord(e->ev_dec[cur], sD));
             }
             for (hipStream_t q : e->stage_stream) {  // the last decoder implies every earlier stage, but the join costs nothing
                 HIPCHECK(e, hipEventRecord(e->ev_join, q));
                 HIPCHECK(e, hipStreamWaitEvent(st, e->ev_join, 0));
             }
-            if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p), T * F, F, 1, e->B, e->yseg.p + c0 * K, Nseg * K, st,
-                                   (int)cn, (long)(mask_n / 2), K))) return rc;
         }
     }
     const long skip = lead;  // CRN.py:587-588
