@@ -48,7 +48,7 @@ __device__ unsigned long long g_x6_trace[16];
 #endif
 
 template <int NTAP, int NT, int CO>
-__global__ __launch_bounds__(256, 2) void k_conv_x6(ConvX6Args xa) {
+__global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa) {
     extern __shared__ __align__(16) uint4 planes[];  // [3][CO][Npos]
     const ConvArgs &a = xa.c;
     constexpr int NPAIR = (NTAP * CO + 1) / 2;  // K steps per chunk
