@@ -71,6 +71,12 @@ int se_load_param(se_engine *e, const char *key, const float *host_data, const i
 /* TemporalCRN.reset() + lazy state allocation for B streams (CRN.py:498-503, 325-326). */
 int se_reset(se_engine *e, int batch);
 
+/* Reset ONE stream of the batch (a call ends, a new caller takes its slot) while the others keep their state: zeroes that
+ * stream's conv time buffers and GRU state, i.e. what TemporalCRN.reset() does (CRN.py:498-503) restricted to row
+ * `stream_index` of every state tensor.  The reference can only reset the whole batch; this is the continuation API a
+ * server needs around the path.  Enqueued on `stream`. */
+int se_reset_stream(se_engine *e, int stream_index, void *stream);
+
 /* One hot-path step: all B streams advance by one K-sample window.
  * wav_in [B, M, K] -> wav_out [B, K]  == istft_trans(forward(stft_trans(x)))  (CRN.py:505-520, 454-496) */
 int se_step(se_engine *e, const float *wav_in, float *wav_out, void *stream);

@@ -117,6 +117,13 @@ class TemporalCRN(nn.Module):
         if self._eng is not None and self._eng.batch > 0:
             self._eng.reset(self._eng.batch)
 
+    def reset_stream(self, index: int):
+        """Extension over the reference (which can only reset the whole batch): reset one stream's conv buffers and GRU
+        state so that a new caller can take that batch slot while the other streams keep their state."""
+        if self._eng is None or self._eng.batch <= 0:
+            raise RuntimeError("reset_stream before any state exists")
+        self._eng.reset_stream(index)
+
     def forward(self, x):
         eng = self._engine_for(x)
         if eng.batch != x.shape[0]:

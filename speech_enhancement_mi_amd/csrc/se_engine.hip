@@ -1148,6 +1148,27 @@ int se_reset(se_engine *e, int batch) {
     return SE_OK;
 }
 
+int se_reset_stream(se_engine *e, int stream_index, void *stream) {
+    if (!e) return SE_ERR_ARG;
+    if (e->B <= 0) return fail(e, SE_ERR_STATE, "se_reset_stream before se_reset");
+    if (stream_index < 0 || stream_index >= e->B) return fail(e, SE_ERR_ARG, "stream index %d outside the batch of %d", stream_index, e->B);
+    HIPCHECK(e, hipSetDevice(e->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int T = e->T, H = e->H, b = stream_index;
+    // conv time buffers = the tail of the current ring slot (the next window reads it as history)
+    for (int i = 0; i < e->L; i++) {
+        const size_t per = (size_t)e->Ch[i] * T * e->F[i];
+        HIPCHECK(e, hipMemsetAsync(e->xin[i][e->slot].p + per * b, 0, per * sizeof(float), st));
+    }
+    for (int i = 0; i < e->npre; i++) {
+        const size_t per = (size_t)e->Ch[0] * T * e->F[0];
+        HIPCHECK(e, hipMemsetAsync(e->pin[i][e->parity].p + per * b, 0, per * sizeof(float), st));
+    }
+    for (int l = 0; l < e->NL; l++)
+        HIPCHECK(e, hipMemsetAsync(e->hbuf[l][e->hcur[l]].p + (size_t)H * b, 0, (size_t)H * sizeof(float), st));
+    return SE_OK;
+}
+
 int se_forward(se_engine *e, const float *x, float *y, void *stream) {
     if (!e || !x || !y) return fail(e, SE_ERR_ARG, "null argument");
     if (e->B <= 0) return fail(e, SE_ERR_STATE, "se_forward before se_reset");

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libse_engine.so")
 SE_MAX_LEVELS = 8
 
 EXPORTS = [
-    "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_step",
+    "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_reset_stream", "se_step",
     "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
@@ -60,6 +60,7 @@ def load_library():
     L.se_last_error.restype = C.c_char_p
     L.se_load_param.argtypes = [vp, C.c_char_p, fp, i64p, C.c_int]
     L.se_reset.argtypes = [vp, C.c_int]
+    L.se_reset_stream.argtypes = [vp, C.c_int, vp]
     L.se_step.argtypes = [vp, fp, fp, vp]
     L.se_realtime_process.argtypes = [vp, fp, C.c_int, C.c_int64, C.c_int, fp, vp]
     L.se_stft.argtypes = [vp, fp, C.c_int, fp, vp]
@@ -160,6 +161,10 @@ class Engine:
     def reset(self, batch: int):
         self._check(self.lib.se_reset(self._h, int(batch)))
         self.batch = int(batch)
+
+    def reset_stream(self, index: int):
+        """Zero the state of ONE stream of the batch (a new caller takes the slot); the others keep streaming."""
+        self._check(self.lib.se_reset_stream(self._h, int(index), self._stream()))
 
     def step(self, wav_in, wav_out=None):
         import torch

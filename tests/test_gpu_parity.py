@@ -248,6 +248,30 @@ def test_stage_pipeline_equals_serial_variants(monkeypatch):
         assert np.array_equal(e_piped.realtime_process(x).cpu().numpy(), ref), variant
 
 
+def test_reset_single_stream_keeps_the_others():
+    """se_reset_stream (streams joining / leaving the batch): after resetting stream 1 only, stream 1 behaves
+    like a freshly reset engine and stream 0 like an engine that was never touched."""
+    cfg = FULL400
+    e, e_fresh, e_cont = _engine(cfg, seed=3), _engine(cfg, seed=3), _engine(cfg, seed=3)
+    a, _ = synth.synth_utterances(2, 3200 * 3, 3, seed=41)
+    bnew, _ = synth.synth_utterances(1, 3200 * 2, 3, seed=42)
+    e.reset(2); e_cont.reset(2); e_fresh.reset(1)
+    for k in range(3):  # both streams hear utterance a
+        w = _cuda(a[:, :, 3200 * k:3200 * (k + 1)])
+        e.step(w); e_cont.step(w)
+    e.reset_stream(1)
+    for k in range(2):  # stream 0 goes on with (a repeat of) a, stream 1 is a new caller with bnew
+        w0 = a[:1, :, 3200 * k:3200 * (k + 1)]
+        w1 = bnew[:, :, 3200 * k:3200 * (k + 1)]
+        y = e.step(_cuda(np.concatenate([w0, w1], 0))).cpu().numpy()
+        y_cont = e_cont.step(_cuda(np.concatenate([w0, w0], 0))).cpu().numpy()
+        y_fresh = e_fresh.step(_cuda(w1)).cpu().numpy()
+        assert rel_rms(y[1], y_fresh[0]) < 2e-6, k
+        assert np.array_equal(y[0], y_cont[0]), k
+    with pytest.raises(RuntimeError):
+        e.reset_stream(2)
+
+
 def test_fft_kernels_exact_under_coexecution(monkeypatch):
     """Regression test for the packed-FP32 co-residency fault (csrc/se_aux.hip): the STFT / iSTFT of one
     engine must stay bit-exact while an unrelated engine runs its MFMA kernels on another stream.  Before the FFT
