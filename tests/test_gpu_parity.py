@@ -223,6 +223,20 @@ def test_stage_pipeline_equals_serial(batch, monkeypatch):
     assert np.array_equal(e_piped.realtime_process(x2, flag=True).cpu().numpy(), ref2)
 
 
+def test_stage_pipeline_long_utterance_crosses_chunks(monkeypatch):
+    """More than kPipeChunk = 64 segments (7 s -> 72 segments): the pipelined path drains and re-forks at the chunk
+    boundary and reuses its spectrum / mask staging buffers; ragged sub-batches of the (i)STFT launches included."""
+    monkeypatch.setenv("SE_GRU_DIRECT", "1")
+    monkeypatch.setenv("SE_PIPELINE", "0")
+    e_serial = _engine(FULL400, seed=7)
+    monkeypatch.setenv("SE_PIPELINE", "1")
+    e_piped = _engine(FULL400, seed=7)
+    mix, _ = synth.synth_utterances(2, 16000 * 7 + 123, 3, seed=35)
+    x = _cuda(mix)
+    ref = e_serial.realtime_process(x).cpu().numpy()
+    assert np.array_equal(e_piped.realtime_process(x).cpu().numpy(), ref)
+
+
 def test_stage_pipeline_default_kernels_within_tolerance(monkeypatch):
     """Default configuration: pipelined (k_gru_step in the overlapped stage) vs single stream (k_gru_step2)."""
     monkeypatch.setenv("SE_PIPELINE", "0")
