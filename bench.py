@@ -205,6 +205,8 @@ def main():
                     help="train = BASELINE configs[3]: data-parallel training step (torch autograd + flat-bucket RCCL all-reduce)")
     ap.add_argument("--utts", type=int, default=8, help="--mode train: utterances per GPU per optimizer step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="f32 = fp32-accurate contractions (headline); f16 = fp16 MFMA operands, fp32 accumulate (BASELINE config 5: --model student --dtype f16 --batch 1024)")
     args = ap.parse_args()
 
     import torch
@@ -235,7 +237,7 @@ def main():
     spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=variant)
     sd = synth.make_state_dict(spec, seed=0)
     eng = engine.Engine(engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], 3200, 2, 3, 3, 16000, 25, 10, args.nfft,
-                                           variant=variant), local_rank)
+                                           variant=variant, precision=1 if args.dtype == "f16" else 0), local_rank)
     eng.load_state_dict(sd)
 
     B, L = args.batch, int(args.seconds * 16000)
@@ -290,9 +292,10 @@ def main():
     # k_conv_x6 / k_gemm_bf16x6 produce fp32-accurate results from 6 bf16 MFMAs per product: `achieved`
     # counts ALGORITHMIC fp32 FLOPs and is priced against the fp32 matrix peak, the peak of the dtype the path computes in;
     # the bf16 matrix-core work actually executed is 6x that and is reported next to the bf16 dense peak.
-    x6 = dom in ("k_conv_x6", "k_gemm_bf16x6")
-    roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / FP32_MATRIX_PEAK_TFLOPS, traffic=pmc_traffic(dom, args),
+    x6 = dom in ("k_conv_x6", "k_gemm_bf16x6") and args.dtype == "f32"
+    peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else 2500.0  # fp16 operands: priced against the dense fp16 matrix peak
+    roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s",
+                    frac=achieved / peak, traffic=pmc_traffic(dom, args) if args.dtype == "f32" else None,
                     executed_bf16_tflops=(6.0 * achieved if x6 else None), bf16_dense_peak=(2500.0 if x6 else None),
                     avg_launch_us=1e3 * d["ms"] / max(1, d["launches"]), launches_per_step=d["launches"],
                     flops_per_launch=d["flops"] / max(1, d["launches"]),
@@ -304,7 +307,7 @@ def main():
 
     result = dict(metric="streaming frames/sec @ b256 (CRN, 3200-samp 16 kHz)", value=value, unit="frames/s",
                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
-                  higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                  higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                   config=dict(workload=f"TemporalCRN ({args.model}) realtime_process, batch {B} streams/GPU, {args.nfft}-pt STFT / {cfg['num_freqs']} bins, hop 160, "
                                        f"{args.seconds:g} s utterances ({nseg} frames of 3200 samples per stream), hash-generated weights",
                               streams_per_gpu=B, frames_per_stream=nseg, n_fft=args.nfft, parallelism=f"streams sharded x{world}, no collective",

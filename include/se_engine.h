@@ -53,6 +53,9 @@ typedef struct {
                                            three 5x5 frequency-dilated preconv blocks, atan2 phase; CRN_ELU.py:321-365);
                                            2 = distillation_crn.py TemporalCRN, the student architecture (as 1, but arctan
                                            phase and gLN denominator sqrt(var)+eps; distillation_crn.py:51,340) */
+    int32_t precision;                  /* 0 = fp32-accurate contractions (6-term split-bf16 MFMA); 1 = fp16 MFMA operands with
+                                           fp32 accumulation for the convolutions and dense layers (the `.half()` / autocast
+                                           inference mode of BASELINE config 5).  Storage and the recurrence stay fp32. */
 } se_config;
 
 typedef struct se_engine se_engine;

@@ -94,6 +94,7 @@ class TemporalCRN(nn.Module):
         self.gru = _Seq(size, hidden, num_layers)
         self._eng: Optional[_engine.Engine] = None
         self._eng_device = None
+        self._eng_precision = 0
         self._versions = None
 
     # ---- engine plumbing -------------------------------------------------------------------------------
@@ -102,9 +103,12 @@ class TemporalCRN(nn.Module):
             raise RuntimeError("TemporalCRN runs on the MI355X engine only: move the model and inputs to the GPU "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
         dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
-        if self._eng is None or self._eng_device != dev:
-            self._eng = _engine.Engine(_engine.make_config(**self._cfg_args), dev)
+        # model.half() (the fp16 inference idiom, BASELINE config 5) selects fp16 MFMA operands in the engine
+        precision = 1 if next(self.parameters()).dtype == torch.float16 else 0
+        if self._eng is None or self._eng_device != dev or self._eng_precision != precision:
+            self._eng = _engine.Engine(_engine.make_config(**self._cfg_args, precision=precision), dev)
             self._eng_device = dev
+            self._eng_precision = precision
             self._versions = None
         versions = tuple(p._version for p in self.parameters())
         if versions != self._versions:  # weights changed (load_state_dict, optimizer step, ...): re-upload

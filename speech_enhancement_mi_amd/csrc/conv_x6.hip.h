@@ -47,9 +47,14 @@ __device__ unsigned long long g_x6_trace[16];
 #define X6T(i)
 #endif
 
-template <int NTAP, int NT, int CO>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// PL = operand planes: 3 = fp32-accurate bf16x6 (six cross terms per product); 1 = plain fp16 operands with fp32
+// accumulation (se_config.precision = 1: the fp16 inference mode of BASELINE config 5, 6x fewer MFMAs, a third of the LDS
+// traffic; operands rounded to 11 mantissa bits)
+template <int NTAP, int NT, int CO, int PL>
 __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa) {
-    extern __shared__ __align__(16) uint4 planes[];  // [3][CO][Npos]
+    extern __shared__ __align__(16) uint4 planes[];  // [PL][CO][Npos]
     const ConvArgs &a = xa.c;
     constexpr int NPAIR = (NTAP * CO + 1) / 2;  // K steps per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
     };
     issue_loads(0);
     const uint4 *wxw = xa.wx + (long)mt * 64 + l31 * 2 + half;  // + (((ch*NPAIR + pr)*3 + plane)*MT) * 64
-    const long wx_plane = (long)MT * 64, wx_pair = 3 * wx_plane, wx_chunk = NPAIR * wx_pair;
+    const long wx_plane = (long)MT * 64, wx_pair = PL * wx_plane, wx_chunk = NPAIR * wx_pair;
 
 #ifdef SE_X6_TRACE
     unsigned long long tr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -153,33 +158,40 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
             if (item < CO * Npos) {
                 const bool ok = (okmask >> k) & 1u;
                 const int cbase = ch * 8 * CO + (CO > 1 ? (int)((octs >> (2 * k)) & 3u) * 8 : 0);
-                __bf16 h[8], m[8], l[8];
+                if (PL == 3) {
+                    __bf16 h[8], m[8], l[8];
 #pragma unroll
-                for (int c = 0; c < 8; c++) split3((ok && cbase + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
-                planes[item] = pack_bf16x8(h);
-                planes[CO * Npos + item] = pack_bf16x8(m);
-                planes[2 * CO * Npos + item] = pack_bf16x8(l);
+                    for (int c = 0; c < 8; c++) split3((ok && cbase + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
+                    planes[item] = pack_bf16x8(h);
+                    planes[CO * Npos + item] = pack_bf16x8(m);
+                    planes[2 * CO * Npos + item] = pack_bf16x8(l);
+                } else {
+                    f16x8 hv;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) hv[c] = (_Float16)((ok && cbase + c < a.Ci) ? pv[k][c] : 0.0f);
+                    planes[item] = __builtin_bit_cast(uint4, hv);
+                }
             }
         }
         X6T(3);
         __syncthreads();
         X6T(4);
         const uint4 *wc = wxw + ch * wx_chunk;
-        uint4 fa_n[3];
+        uint4 fa_n[PL];
 #pragma unroll
-        for (int p = 0; p < 3; p++) fa_n[p] = wc[p * wx_plane];
+        for (int p = 0; p < PL; p++) fa_n[p] = wc[p * wx_plane];
 #ifdef SE_X6_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         X6T(5);
 #endif
 #pragma unroll
         for (int pr = 0; pr < NPAIR; pr++) {
-            bf16x8 fa[3];
+            uint4 fa[PL];
 #pragma unroll
-            for (int p = 0; p < 3; p++) fa[p] = __builtin_bit_cast(bf16x8, fa_n[p]);
+            for (int p = 0; p < PL; p++) fa[p] = fa_n[p];
             if (pr + 1 < NPAIR) {
 #pragma unroll
-                for (int p = 0; p < 3; p++) fa_n[p] = wc[(pr + 1) * wx_pair + p * wx_plane];
+                for (int p = 0; p < PL; p++) fa_n[p] = wc[(pr + 1) * wx_pair + p * wx_plane];
             }
             // vmcnt retires in order: the next chunk's 32 staging loads are issued only after the LAST weight-fragment
             // load of this chunk, otherwise the first in-loop fragment wait would also wait for all of them
@@ -187,16 +199,22 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
 #pragma unroll
             for (int i = 0; i < NT; i++) {
                 const int pos = lane_base[i] + toffL[pr];
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[CO * Npos + pos]);
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
                 f32x16 c = acc[i];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b1, c, 0, 0, 0);  // mid*mid
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b2, c, 0, 0, 0);  // hi*lo
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], b0, c, 0, 0, 0);  // lo*hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b1, c, 0, 0, 0);  // hi*mid
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b0, c, 0, 0, 0);  // mid*hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b0, c, 0, 0, 0);  // hi*hi
+                if (PL == 3) {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[0]), a1 = __builtin_bit_cast(bf16x8, fa[PL > 1 ? 1 : 0]),
+                                 a2 = __builtin_bit_cast(bf16x8, fa[PL > 2 ? 2 : 0]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
+                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[CO * Npos + pos]);
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);  // hi*hi
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, planes[pos]), c, 0, 0, 0);
+                }
                 acc[i] = c;
             }
         }

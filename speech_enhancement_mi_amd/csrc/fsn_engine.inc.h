@@ -150,7 +150,7 @@ int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, lo
     FHIP(e, hipGetLastError());
     {  // fc_output_layer + ReLU (fullsubnet.py:288-290): [B*T, H] -> [B*T, F]
         GemmX6Args g{e->fb_seq.p, reinterpret_cast<const __bf16 *>(e->fb.fcw_x.p), e->fb.fcb.p, e->fb_out.p, B * T, F, e->fb.H, (long)e->fb.H, (long)F, 1};
-        hipLaunchKernelGGL(k_gemm_bf16x6, dim3((F + kGemmBN - 1) / kGemmBN, (B * T + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_gemm_x<3>, dim3((F + kGemmBN - 1) / kGemmBN, (B * T + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, g);
     }
     {  // sub-band input + its CumLayerNorm (fullsubnet.py:796-802)
         FsnUnfoldArgs a{e->mag.p, e->fb_out.p, e->sbin.p, e->part_sb.p, B, T, F, Kp, e->c.sb_neighbors, SI};

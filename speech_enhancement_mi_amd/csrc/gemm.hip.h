@@ -137,9 +137,14 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
     l = (__bf16)r2;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
-    __shared__ __align__(16) __bf16 Ap[3][kGemmBM * kXLd];
-    __shared__ __align__(16) __bf16 Wp[3][kGemmBN * kXLd];
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4g __attribute__((ext_vector_type(4)));
+
+// PL = operand planes: 3 = bf16x6 (fp32-accurate), 1 = fp16 operands (se_config.precision = 1); Wp then holds ONE fp16 plane
+template <int PL>
+__global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
+    __shared__ __align__(16) __bf16 Ap[PL][kGemmBM * kXLd];
+    __shared__ __align__(16) __bf16 Wp[PL][kGemmBN * kXLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     f32x4 qa[4];
-    uint4 qw[6];
+    uint4 qw[2 * PL];
     auto issue = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 4; it++) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
             qa[it] = *reinterpret_cast<const f32x4 *>(a.A + (long)row * a.lda + k);
         }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
+        for (int it = 0; it < 2 * PL; it++) {
             const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
             const int row = min(n0 + r, a.N - 1), k = min(k0 + q, a.K - 8);
             qw[it] = *reinterpret_cast<const uint4 *>(a.Wp + ((long)plane * a.N + row) * a.K + k);
@@ -175,19 +180,26 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
         for (int it = 0; it < 4; it++) {
             const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
             const bool ok = (m0 + r < a.M) && (k0 + kq < a.K);
-            bf16x4 h, m, l;
+            if (PL == 3) {
+                bf16x4 h, m, l;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                __bf16 hh, mm, ll;
-                split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
-                h[e] = hh; m[e] = mm; l[e] = ll;
+                for (int e = 0; e < 4; e++) {
+                    __bf16 hh, mm, ll;
+                    split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
+                    h[e] = hh; m[e] = mm; l[e] = ll;
+                }
+                *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
+                *reinterpret_cast<bf16x4 *>(&Ap[PL > 1 ? 1 : 0][r * kXLd + kq]) = m;
+                *reinterpret_cast<bf16x4 *>(&Ap[PL > 2 ? 2 : 0][r * kXLd + kq]) = l;
+            } else {
+                f16x4g h;
+#pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (_Float16)(ok ? qa[it][e] : 0.0f);
+                *reinterpret_cast<f16x4g *>(&Ap[0][r * kXLd + kq]) = h;
             }
-            *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
-            *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
-            *reinterpret_cast<bf16x4 *>(&Ap[2][r * kXLd + kq]) = l;
         }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
+        for (int it = 0; it < 2 * PL; it++) {
             const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
             const bool ok = (n0 + r < a.N) && (k0 + q < a.K);
             *reinterpret_cast<uint4 *>(&Wp[plane][r * kXLd + q]) = ok ? qw[it] : make_uint4(0, 0, 0, 0);
@@ -196,25 +208,33 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6(GemmX6Args a) {
         if (k0 + kGemmKC < a.K) issue(k0 + kGemmKC);  // next chunk in flight during the MFMAs
 #pragma unroll
         for (int ks = 0; ks < kGemmKC; ks += 16) {
-            bf16x8 fa[2][3], fb[2][3];
+            uint4 fa[2][PL], fb[2][PL];
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    fa[i][p] = *reinterpret_cast<const bf16x8 *>(&Ap[p][(wm + i * 32 + l31) * kXLd + ks + half * 8]);
-                    fb[i][p] = *reinterpret_cast<const bf16x8 *>(&Wp[p][(wn + i * 32 + l31) * kXLd + ks + half * 8]);
+                for (int p = 0; p < PL; p++) {
+                    fa[i][p] = *reinterpret_cast<const uint4 *>(&Ap[p][(wm + i * 32 + l31) * kXLd + ks + half * 8]);
+                    fb[i][p] = *reinterpret_cast<const uint4 *>(&Wp[p][(wn + i * 32 + l31) * kXLd + ks + half * 8]);
                 }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
+                    if (PL == 3) {
+                        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][PL > 1 ? 1 : 0]),
+                                     a2 = __builtin_bit_cast(bf16x8, fa[i][PL > 2 ? 2 : 0]);
+                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][PL > 1 ? 1 : 0]),
+                                     b2 = __builtin_bit_cast(bf16x8, fb[j][PL > 2 ? 2 : 0]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);  // hi*mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);  // mid*hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);  // hi*hi
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, fa[i][0]), __builtin_bit_cast(f16x8g, fb[j][0]), c, 0, 0, 0);
+                    }
                     acc[i][j] = c;
                 }
         }

@@ -102,6 +102,7 @@ struct se_engine {
     DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
+    int precision = 0;        // se_config.precision: 0 = bf16x6 (3 operand planes), 1 = fp16 operands (1 plane)
     int num_cu = 256;         // compute units of the device (MI355X: 256)
     int skip_fuse = 1;        // SE_SKIP_FUSE=0: skip convolution writes both tensors, k_dec_blend_ew applies the gate
     int conv_small16 = 1;     // SE_CONV_SMALL16=0: first encoder block on k_conv_igemm instead of the vector-ALU kernel
@@ -212,6 +213,12 @@ struct ProfScope {  // brackets one launch with two events when profiling is on
     }
 };
 
+uint16_t f16_rne(float x) {  // IEEE half, round to nearest even (the host compiler's _Float16 conversion)
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
 uint16_t bf16_rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -227,6 +234,14 @@ float bf16_to_f32(uint16_t h) {
 // three bf16 planes (hi, mid, lo) of a [rows][cols] fp32 matrix -> device buffer of 3*rows*cols uint16
 int upload_split3(se_engine *e, DevBuf &b, const std::vector<float> &w) {
     const size_t n = w.size();
+    if (e->precision == 1) {  // one fp16 plane
+        std::vector<uint16_t> plane(n);
+        for (size_t i = 0; i < n; i++) plane[i] = f16_rne(w[i]);
+        int rc = dev_alloc(e, b, (n + 1) / 2);
+        if (rc) return rc;
+        HIPCHECK(e, hipMemcpy(b.p, plane.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+        return 0;
+    }
     std::vector<uint16_t> planes(3 * n);
     for (size_t i = 0; i < n; i++) {
         const float x = w[i];
@@ -325,7 +340,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
                 if ((size_t)CO * c_Rmax * St > 256 * kX6PosPerThread) continue;
                 ConvPlan::Geo &g = pl.geo[c_NT - 1];
                 g.NT = c_NT; g.tpw = c_tpw; g.n_wg = c_wg; g.grouped = c_grouped;
-                g.lds = std::max<size_t>((size_t)3 * CO * c_Rmax * St * 16, 64);
+                g.lds = std::max<size_t>((size_t)(e->precision == 1 ? 1 : 3) * CO * c_Rmax * St * 16, 64);
                 tpw = c_tpw; n_wg = c_wg; NT = c_NT; Rmax = c_Rmax; grouped = c_grouped;
             }
             if (NT > 0) break;
@@ -339,10 +354,11 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
             a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = gate_pairs; a.Cy = Cy; a.cy0 = cy0;
             for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
             pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true; pl.CO = CO;
-            pl.lds = std::max<size_t>((size_t)3 * CO * Rmax * St * 16, 64);
+            pl.lds = std::max<size_t>((size_t)(e->precision == 1 ? 1 : 3) * CO * Rmax * St * 16, 64);
             // weights: [chunk][step][plane][mtile][co 32][k 16], k = half*8 + c <-> entry 2*step+half = (tap, octet) tap-major,
             // channel chunk*8*CO + octet*8 + c
-            std::vector<uint16_t> wx((size_t)nchunk * nstep * 3 * MT * 32 * 16, 0);
+            const int PL = e->precision == 1 ? 1 : 3;
+            std::vector<uint16_t> wx((size_t)nchunk * nstep * PL * MT * 32 * 16, 0);
             for (int ch = 0; ch < nchunk; ch++)
                 for (int st = 0; st < nstep; st++)
                     for (int m = 0; m < MT; m++)
@@ -356,9 +372,9 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
                                 const float r1 = x - bf16_to_f32(h);
                                 const uint16_t md = bf16_rne(r1);
                                 const float r2 = r1 - bf16_to_f32(md);
-                                const uint16_t parts[3] = {h, md, bf16_rne(r2)};
-                                for (int pln = 0; pln < 3; pln++)
-                                    wx[(((((size_t)ch * nstep + st) * 3 + pln) * MT + m) * 32 + r) * 16 + k] = parts[pln];
+                                const uint16_t parts[3] = {PL == 1 ? f16_rne(x) : h, md, bf16_rne(r2)};
+                                for (int pln = 0; pln < PL; pln++)
+                                    wx[(((((size_t)ch * nstep + st) * PL + pln) * MT + m) * 32 + r) * 16 + k] = parts[pln];
                             }
             int rc = dev_alloc(e, pl.wx, (wx.size() + 1) / 2);
             if (rc) return rc;
@@ -635,7 +651,10 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
         { const char *want = getenv("SE_X6_TRACE_LABEL"); xa.trace_slot = (want && label && strcmp(want, label) == 0) ? 0 : -1; }
 #endif
 #define SE_X6_CASE(NTAP_, NT_, CO_) \
-    case (NTAP_ * 8 + NT_) * 8 + CO_: hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_>), grid, dim3(256), pl.lds, st, xa); break;
+    case (NTAP_ * 8 + NT_) * 8 + CO_: \
+        if (e->precision == 1) hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_, 1>), grid, dim3(256), pl.lds, st, xa); \
+        else hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_, 3>), grid, dim3(256), pl.lds, st, xa); \
+        break;
 #define SE_X6_TAPS(NTAP_, CO_) SE_X6_CASE(NTAP_, 1, CO_) SE_X6_CASE(NTAP_, 2, CO_) SE_X6_CASE(NTAP_, 3, CO_) SE_X6_CASE(NTAP_, 4, CO_)
         switch ((a.ntap * 8 + pl.NT) * 8 + pl.CO) {
             SE_X6_TAPS(15, 1) SE_X6_TAPS(9, 1) SE_X6_TAPS(6, 1) SE_X6_TAPS(1, 1) SE_X6_TAPS(1, 2) SE_X6_TAPS(1, 4)
@@ -667,9 +686,10 @@ int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw
                 int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label, const float *Wx = nullptr) {
     dim3 ggrid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
     if (Wx && e->gemm_mode == 6 && Kd % 8 == 0 && Kd >= 8 && lda % 4 == 0 && ldw == Kd) {
-        ProfScope ps(e, "k_gemm_bf16x6", label, 2.0 * Mr * Nc * Kd, st);
+        ProfScope ps(e, e->precision == 1 ? "k_gemm_f16" : "k_gemm_bf16x6", label, 2.0 * Mr * Nc * Kd, st);
         GemmX6Args g{A, reinterpret_cast<const __bf16 *>(Wx), bias, C, Mr, Nc, Kd, lda, ldc, relu};
-        hipLaunchKernelGGL(k_gemm_bf16x6, ggrid, dim3(256), 0, st, g);
+        if (e->precision == 1) hipLaunchKernelGGL(k_gemm_x<1>, ggrid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_gemm_x<3>, ggrid, dim3(256), 0, st, g);
         HIPCHECK(e, hipGetLastError());
         return 0;
     }
@@ -910,7 +930,7 @@ int ensure_ready(se_engine *e) {
 
 extern "C" {
 
-int se_abi_version(void) { return 1; }
+int se_abi_version(void) { return 2; }
 
 const char *se_last_error(const se_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -933,6 +953,8 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     e->device = device;
     e->L = L; e->M = cfg->num_inputs; e->K = cfg->segment_length; e->N = cfg->n_fft; e->H = cfg->hidden; e->NL = cfg->num_layers;
     if (cfg->variant < 0 || cfg->variant > 2) { delete e; return fail(nullptr, SE_ERR_ARG, "variant %d unknown (0 CRN, 1 CRN_ELU, 2 student)", cfg->variant); }
+    if (cfg->precision < 0 || cfg->precision > 1) { delete e; return fail(nullptr, SE_ERR_ARG, "precision %d unknown (0 fp32-accurate, 1 fp16 operands)", cfg->precision); }
+    e->precision = cfg->precision;
     e->variant = cfg->variant;
     e->act = cfg->variant ? 2 : 1;
     e->npre = cfg->variant ? 3 : 0;
@@ -990,10 +1012,10 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
 #undef SE_CONV_ATTR
 #define SE_X6_ATTR(NTAP_, CO_)                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SE_X6_ATTR(15, 1) SE_X6_ATTR(9, 1) SE_X6_ATTR(6, 1) SE_X6_ATTR(1, 1) SE_X6_ATTR(1, 2) SE_X6_ATTR(1, 4)
 #undef SE_X6_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);

@@ -29,7 +29,7 @@ class SeConfig(C.Structure):
     _fields_ = [("num_levels", C.c_int32), ("channels", C.c_int32 * SE_MAX_LEVELS), ("num_freqs", C.c_int32),
                 ("hidden", C.c_int32), ("num_layers", C.c_int32), ("num_inputs", C.c_int32),
                 ("kernel_size", C.c_int32), ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32),
-                ("segment_length", C.c_int32), ("variant", C.c_int32)]
+                ("segment_length", C.c_int32), ("variant", C.c_int32), ("precision", C.c_int32)]
 
 
 class FsnConfig(C.Structure):
@@ -91,7 +91,7 @@ def load_library():
 
 
 def make_config(num_channels, num_freqs, hidden, segment_length, num_layers=1, num_inputs=3, kernel_size=3,
-                sample_rate=16000, win_length=25, hop_length=10, n_fft=400, variant=0) -> SeConfig:
+                sample_rate=16000, win_length=25, hop_length=10, n_fft=400, variant=0, precision=0) -> SeConfig:
     cfg = SeConfig()
     if len(num_channels) > SE_MAX_LEVELS:
         raise ValueError("too many levels")
@@ -104,6 +104,7 @@ def make_config(num_channels, num_freqs, hidden, segment_length, num_layers=1, n
     cfg.hop = int(round(sample_rate / 1000.0 * hop_length))
     cfg.segment_length = int(segment_length)
     cfg.variant = int(variant)
+    cfg.precision = int(precision)  # 0 = fp32-accurate contractions, 1 = fp16 MFMA operands (model.half())
     return cfg
 
 
