@@ -1421,7 +1421,11 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
     const long gap = K - (P + Lp % K) % K;               // utility.py:327-329
     const long Nseg = 2 * (Lp + gap + P) / K;            // utility.py:360-368
     if ((rc = dev_alloc(e, e->yseg, (size_t)batch * Nseg * K))) return rc;
-    const bool piped = e->pipeline && !e->prof_on && Nseg > 1;
+    bool piped = e->pipeline && !e->prof_on && Nseg > 1;
+    if (piped && ensure_stage_streams(e)) {  // no extra streams / events available: fall back to the caller's stream for good
+        e->pipeline = 0;
+        piped = false;
+    }
     if (!piped) {
         for (long n = 0; n < Nseg; n++) {
             // segment n covers padded[n*P, n*P+K) with padded = [0]*P | [0]*lead | x | zeros
@@ -1433,7 +1437,6 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         // Segments are sequentially dependent only WITHIN a stage (conv history, GRU state), so the three stages run as a
         // software pipeline over segments on three streams: while the bottleneck of segment n walks its 2 x T dependent
         // GRU launches, the encoder of n+1.. and the decoder of n-1 keep the matrix cores and HBM busy.
-        if ((rc = ensure_stage_streams(e))) return rc;
         hipStream_t sE = e->stage_stream[0], sG = e->stage_stream[1], sD = e->stage_stream[2];
         const long F = e->F[0], T = e->T, M = e->M;
         const size_t spec_n = (size_t)e->B * M * T * F * 2, mask_n = (size_t)e->B * T * F * 2;
