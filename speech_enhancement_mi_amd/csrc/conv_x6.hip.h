@@ -146,6 +146,16 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
 #endif
     for (int ch = 0; ch < a.nchunk; ch++) {
         X6T(0);
+        // The weight fragments of the chunk's first K step are requested before the staging phase where registers allow
+        // (<= 9 taps), which hides their latency: requested after the second barrier they cost 6-13 k exposed cycles per
+        // workgroup (phase trace); the 15-tap instances are at the register limit and spill when the request moves up.
+        constexpr bool kEarlyA = NTAP <= 9;
+        const uint4 *wc = wxw + ch * wx_chunk;
+        uint4 fa_n[PL];
+        if (kEarlyA) {
+#pragma unroll
+            for (int p = 0; p < PL; p++) fa_n[p] = wc[p * wx_plane];
+        }
         __syncthreads();  // previous chunk fully consumed
         X6T(1);
 #ifdef SE_X6_TRACE
@@ -176,10 +186,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
         X6T(3);
         __syncthreads();
         X6T(4);
-        const uint4 *wc = wxw + ch * wx_chunk;
-        uint4 fa_n[PL];
+        if (!kEarlyA) {
 #pragma unroll
-        for (int p = 0; p < PL; p++) fa_n[p] = wc[p * wx_plane];
+            for (int p = 0; p < PL; p++) fa_n[p] = wc[p * wx_plane];
+        }
 #ifdef SE_X6_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         X6T(5);
