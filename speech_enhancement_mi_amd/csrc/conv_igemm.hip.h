@@ -51,6 +51,11 @@ struct ConvArgs {
     // (CRN_ELU.py:240: out = conv_trans(out) * sigmoid(conv_gated(out))); the epilogue writes channel c = trans * sigmoid(gated)
     int gate_pairs;
     int Cy, cy0;           // channels of y per stream and channel offset of this launch (row -> channel cy0 + row[/2])
+    // par_rows: GEMM rows (2c, 2c+1) are the EVEN and ODD output-frequency parity of channel c of a transposed convolution
+    // whose two tap sets were merged into one launch (weights are zero where a parity does not use a tap): row 2c+p is
+    // stored at column os*m + oo + p of channel c.  Used for narrow decoder blocks (<= 16 channels), where each parity alone
+    // would leave half of the 32-row MFMA tile empty.
+    int par_rows;
     // k_conv_small only: fused gated 1x1 pair on the activated outputs (all Co channels of a position live in one
     // thread): gatew = [trans Co x Co | gated Co x Co | trans bias Co | gated bias Co], nullptr = off
     const float *gatew;
@@ -176,8 +181,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
                 if (co < a.Co) {
                     float v = acc[i][r] + bv[r];
                     if (co >= a.relu_lo && co < a.relu_hi) v = conv_act(v, a.act);
-                    if (a.y) yp[co * ys_c] = v;  // y == nullptr: statistics-only pass
-                    if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
+                    if (a.par_rows) {
+                        const int par = co & 1;
+                        if (a.os * pos_m[i] + a.oo + par < a.Fy) {  // the odd parity has one column less
+                            yp[(co >> 1) * ys_c + par] = v;
+                            ssum += v; ssq += v * v;
+                        }
+                    } else {
+                        if (a.y) yp[co * ys_c] = v;  // y == nullptr: statistics-only pass
+                        if (co >= a.stats_lo && co < a.stats_hi) { ssum += v; ssq += v * v; }
+                    }
                 }
             }
         }

@@ -104,6 +104,7 @@ struct se_engine {
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
     int precision = 0;        // se_config.precision: 0 = bf16x6 (3 operand planes), 1 = fp16 operands (1 plane)
     int num_cu = 256;         // compute units of the device (MI355X: 256)
+    int dec_merge = 1;        // SE_DEC_MERGE=0: narrow decoder blocks as two parity launches like the wide ones
     int skip_fuse = 1;        // SE_SKIP_FUSE=0: skip convolution writes both tensors, k_dec_blend_ew applies the gate
     int conv_small16 = 1;     // SE_CONV_SMALL16=0: first encoder block on k_conv_igemm instead of the vector-ALU kernel
     int conv_geo_fixed = 0;   // SE_CONV_GEO_FIXED=1: always the largest k_conv_x6 tiling (no per-batch selection)
@@ -285,6 +286,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
               WSel wsel, const std::vector<float> &bias, int relu_lo, int relu_hi, int act = 1, int gate_pairs = 0, int Cy = -1,
               int cy0 = 0) {
     if (Cy < 0) Cy = Co;
+    pl.a.par_rows = 0;
     pl.x6 = false;
     pl.active = FP > 0;
     if (!pl.active) return 0;
@@ -485,13 +487,31 @@ int prepare_weights(se_engine *e) {
             for (int kt = 0; kt < 3; kt++) te.push_back({kf, kt, 2 - kt, 2 - kf / 2});
         for (int kf = 1; kf < 5; kf += 2)
             for (int kt = 0; kt < 3; kt++) to.push_back({kf, kt, 2 - kt, 1 + (3 - kf) / 2});
-        int rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, te, wsel, *b, 0, Co, e->act);
-        if (rc) return rc;
-        rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 3, d, Fi + 2, to, wsel, *b, 0, Co, e->act);
-        if (rc) return rc;
+        int rc = 0;
+        bool merged = false;
+        if (e->dec_merge && Co > 4 && Co <= 16 && e->conv_mode == 6) {
+            // narrow block: both parities in ONE 15-tap launch, rows (2c, 2c+1) = (even, odd) parity of channel c (ConvArgs::par_rows)
+            std::vector<std::array<int, 4>> tu;
+            for (int kf = 0; kf < 5; kf++)
+                for (int kt = 0; kt < 3; kt++) tu.push_back({kf, kt, 2 - kt, (kf & 1) ? 1 + (3 - kf) / 2 : 2 - kf / 2});
+            std::vector<float> bias2(2 * Co);
+            for (int c = 0; c < Co; c++) bias2[2 * c] = bias2[2 * c + 1] = (*b)[c];
+            rc = plan_conv(e, e->lv[j].dec_even, Ci, 2 * Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, tu,
+                           [=](int ci, int row, int kf, int kt) { return ((row & 1) == (kf & 1)) ? wsel(ci, row >> 1, kf, kt) : 0.0f; },
+                           bias2, 0, 2 * Co, e->act, 0, /*Cy=*/Co, 0);
+            if (rc) return rc;
+            merged = e->lv[j].dec_even.x6;
+            if (merged) { e->lv[j].dec_even.a.par_rows = 1; e->lv[j].dec_odd.active = false; e->lv[j].dec_odd.grid_x = 0; }
+        }
+        if (!merged) {
+            rc = plan_conv(e, e->lv[j].dec_even, Ci, Co, Fi, Fi, Fo, 1, 2, 0, 1, 0, 3, d, Fi + 2, te, wsel, *b, 0, Co, e->act);
+            if (rc) return rc;
+            rc = plan_conv(e, e->lv[j].dec_odd, Ci, Co, Fi - 1, Fi, Fo, 1, 2, 1, 1, 0, 3, d, Fi + 2, to, wsel, *b, 0, Co, e->act);
+            if (rc) return rc;
+        }
         // SURVEY 8d counts a transposed conv as Cin*Cout*15*Fi*T MACs; split 9:6 over the two parity launches
-        e->lv[j].dec_even.flops = 2.0 * Ci * Co * 9 * Fi * e->T;
-        e->lv[j].dec_odd.flops = 2.0 * Ci * Co * 6 * Fi * e->T;
+        e->lv[j].dec_even.flops = 2.0 * Ci * Co * (merged ? 15 : 9) * Fi * e->T;
+        e->lv[j].dec_odd.flops = merged ? 0.0 : 2.0 * Ci * Co * 6 * Fi * e->T;
         if ((rc = dev_upload(e, e->lv[j].dec_nw, *nw))) return rc;
         if ((rc = dev_upload(e, e->lv[j].dec_nb, *nb))) return rc;
         if (lvl > 0) {  // skip path exists (CRN.py:485-487)
@@ -980,6 +1000,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_PIPELINE")) e->pipeline = atoi(s);
     if (const char *s = getenv("SE_CONV_SMALL16")) e->conv_small16 = atoi(s);
     if (const char *s = getenv("SE_SKIP_FUSE")) e->skip_fuse = atoi(s);
+    if (const char *s = getenv("SE_DEC_MERGE")) e->dec_merge = atoi(s);
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) e->num_cu = ncu;
