@@ -4,17 +4,27 @@
 A "step" is one realtime_process call (the hot path) over one batch of B synthetic 3 s, 16 kHz,
 3-microphone utterances already resident in HBM: B x Nseg frames (Nseg = 34 windows of 3200 samples per stream,
 including the reference's K/2 left pad and gap padding).  value = frames / s summed over all ranks.
-N > 1: one process per GPU, streams sharded across ranks (independent units: no data-path collective, weak
-scaling); barrier + synchronize on both sides of the timed region, MAX over ranks.
+
+Multi-GPU (`--gpus N`, N > 1): one process per GPU, streams sharded across ranks (independent units: no data-path
+collective, weak scaling); barrier + synchronize on both sides of the timed region, MAX over ranks over RCCL.
+  * launched by the driver through `python -m torch.distributed.run ... bench.py --gpus N`: RANK is in the environment
+    and this process IS rank RANK;
+  * launched plainly as `python bench.py --gpus N`: this process is only the PARENT - it never touches the GPU (no
+    torch.cuda / HIP call, no exec), spawns the N ranks through torch.distributed.run as a child process and exits
+    with the child's code.  Fewer than N visible devices -> non-zero exit with a message, never a silent fallback.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream in an extra
-profiled step after the timed region) and `cpu_baseline` (the C oracle timed on the host cores, N=1 only).
+profiled step after the timed region) and `cpu_baseline` (the C oracle timed on the host cores, N=1 only) plus
+`cpu_baseline_torch` (the PyTorch-CPU restatement at B = 1 and 32, all cores, best of 3).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,21 +34,114 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 dense peak
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (spec)
 
 
-MODELS = {  # name -> (variant, num_channels, hidden): reference CRN.py / CRN_ELU.py / distillation_crn.py student
-    "crn": (0, [16, 32, 64, 128], 512),
-    "crn_elu": (1, [16, 32, 64, 128], 512),
-    "student": (2, [16, 32, 64, 64], 128),
+MODELS = {  # name -> (variant, num_channels, hidden, label): reference CRN.py / CRN_ELU.py / distillation_crn.py student
+    "crn": (0, [16, 32, 64, 128], 512, "CRN"),
+    "crn_elu": (1, [16, 32, 64, 128], 512, "CRN_ELU"),
+    "student": (2, [16, 32, 64, 64], 128, "distilled CRN_ELU student"),
 }
+PRECISIONS = {"f32": 0, "f16": 1, "bf16x3": 2}  # se_config.precision
 
 
 def crn_cfg(nfft, model="crn"):
-    _, ch, hid = MODELS[model]
+    _, ch, hid, _ = MODELS[model]
     return dict(num_channels=ch, num_freqs=nfft // 2 + 1, hidden=hid, segment_length=3200, num_layers=2,
                 num_inputs=3, kernel_size=3, sample_rate=16000, win_length=25, hop_length=10, n_fft=nfft)
 
 
+def seg_count(L, K=3200):
+    """Frames per stream of realtime_process(flag=False): K/2 left pad + the reference's gap padding (utility.py:312-370)."""
+    P = K // 2
+    Lp = L + P
+    gap = K - (P + Lp % K) % K
+    return 2 * (Lp + gap + P) // K
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no RANK in the environment
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_gpus():
+    """Device count WITHOUT initialising HIP in this process (torch.cuda.device_count() does not, on this image)."""
+    import torch
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run: spawn `torch.distributed.run` as a CHILD process (this process has not touched the GPU and
+    never will) and return its exit code."""
+    fake = os.environ.get("SE_BENCH_SELFTEST") == "1"  # CPU rehearsal of the launcher path (tests/test_bench_launcher.py)
+    if not fake:
+        ndev = visible_gpus()
+        if ndev < n:
+            print(f"bench.py: --gpus {n} requested but only {ndev} GPU(s) are visible; refusing to run "
+                  f"(one process per GPU over RCCL, no silent fallback)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_world(args):
+    """(rank, local_rank, world, backend).  N > 1: RCCL (`nccl`) with one device per rank; anything else is refused."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SE_BENCH_SELFTEST") == "1":
+        return rank, local_rank, world, "gloo"
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible; refusing (no gloo / shared-device fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+    return rank, local_rank, world, "nccl" if world > 1 else "none"
+
+
+def launcher_selftest(args):
+    """CPU-only rehearsal of the N-rank plumbing (SE_BENCH_SELFTEST=1): gloo world, barrier, MAX over ranks, one JSON line
+    from rank 0.  Exercises exactly the spawn / env / reduction path of a real run; no engine, no timing claim."""
+    import torch
+    import torch.distributed as dist
+    rank, _, world, backend = init_world(args)
+    if os.environ.get("SE_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)  # rehearses a dying rank: the parent must exit non-zero
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    from speech_enhancement_mi_amd.sharding import shard_streams
+    lo, hi = shard_streams(args.batch * world, rank, world)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(selftest=True, n_gpus=world, backend=backend, max_over_ranks=float(t.item()), rank0_streams=[lo, hi])))
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# baselines and roofline helpers
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(cfg, sd, variant=0, seconds_budget=20.0):
     """Oracle (C restatement of the reference path, OpenMP) on the host cores, bounded sample."""
     from oracle import crn_oracle as orc
@@ -51,10 +154,7 @@ def cpu_baseline(cfg, sd, variant=0, seconds_budget=20.0):
     o.load_state_dict(sd)
     B, L = max(2, cores), 8000
     mix, _ = synth.synth_utterances(B, L, 3, seed=99)
-    P, K = 1600, 3200
-    Lp = L + P
-    gap = K - (P + Lp % K) % K
-    nseg = 2 * (Lp + gap + P) // K
+    nseg = seg_count(L)
     o.realtime_process(mix[:1, :, :3200])  # warm
     reps, t0 = 0, time.time()
     while True:
@@ -67,27 +167,109 @@ def cpu_baseline(cfg, sd, variant=0, seconds_budget=20.0):
                 sample=f"{reps} x realtime_process of {B} streams x {L} samples ({nseg} frames each), C oracle, OpenMP {cores} threads of {avail} available")
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
-    in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950 it reports half
-    of a wide coalesced read).  Only valid for the default workload; None otherwise or if the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_bench_b256_nfft512_pmc_hbm.csv")
-    if not os.path.exists(path) or args.batch != 256 or args.nfft != 512 or args.model != "crn":
-        return None
-    import csv
-    fetch = write = nf = nw = 0.0
-    for row in csv.DictReader(open(path)):
-        if kernel + "<" in row["kernel"] or row["kernel"].endswith("::" + kernel) or ("::" + kernel + "(") in row["kernel"]:
-            if row["counter"] == "FETCH_SIZE":
-                fetch += float(row["sum_KB"]); nf += float(row["launches"])
-            elif row["counter"] == "WRITE_SIZE":
-                write += float(row["sum_KB"]); nw += float(row["launches"])
-    if nf == 0 or nw == 0:
-        return None
-    return (2.0 * fetch / nf + write / nw) * 1024.0
+def cpu_baseline_torch(cfg, sd, seconds_budget=30.0):
+    """SURVEY.md 8d / BASELINE.md 3: the PyTorch-CPU restatement of the path (speech_enhancement_mi_amd.training.TrainableCRN,
+    pinned against the oracle in tests/test_training_cpu.py) under no_grad on all host cores, B in {1, 32}, 3 s utterances,
+    one warm-up utterance, best of 3.  Variant 0 (CRN.py) only."""
+    import torch
+    from speech_enhancement_mi_amd import synth
+    from speech_enhancement_mi_amd.training import TrainableCRN
+    avail = len(os.sched_getaffinity(0))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(avail)
+    model = TrainableCRN(**cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    out = []
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    t_all = time.time()
+    with torch.no_grad():
+        for B in (1, 32):
+            mix, _ = synth.synth_utterances(B, 48000, 3, seed=7)
+            x = torch.from_numpy(mix)
+            model.realtime_process_train(x[:1])  # warm-up utterance
+            best = None
+            for _ in range(3):
+                t0 = time.time()
+                model.realtime_process_train(x)
+                dt = time.time() - t0
+                best = dt if best is None else min(best, dt)
+                if time.time() - t_all > seconds_budget:
+                    break
+            nseg = seg_count(48000)
+            out.append(dict(batch=B, value=B * nseg / best, unit="frames/s", realtime_factor=B * 3.0 / best, cores=avail, kind="port",
+                            cpu=cpu_model, sample=f"best of <=3 realtime_process of {B} x 3 s utterances ({nseg} frames each), torch {torch.__version__} CPU, {avail} threads"))
+    torch.set_num_threads(prev)
+    return out
 
 
-def bench_train(args, rank, local_rank, world):
+def kernel_source_sha():
+    """sha256 over the kernel sources: stamps the committed PMC summary so a stale one is refused."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "speech_enhancement_mi_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS source state (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950
+    it reports half of a wide coalesced read).  profiles/pmc_hbm_current.json = {"src_sha", "workload", "kernels": {name:
+    {"fetch_kb", "write_kb"}}} is written by profiles/summarize.py; a summary made from other kernel sources (sha mismatch)
+    or another workload is refused and traffic is null."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_current.json")
+    if not os.path.exists(path):
+        return None, "no PMC summary committed for this source state"
+    d = json.load(open(path))
+    if d.get("src_sha") != kernel_source_sha():
+        return None, f"PMC summary is from kernel sources {d.get('src_sha')}, current {kernel_source_sha()}: refused"
+    if d.get("workload") != workload_key:
+        return None, f"PMC summary is for workload {d.get('workload')}"
+    k = d["kernels"].get(kernel)
+    if not k:
+        return None, "kernel not in PMC summary"
+    return (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0, d.get("source", "")
+
+
+def timed_region(fn, steps, warmup, world, backend):
+    """W untimed calls, then K calls bracketed by barrier + synchronize on both sides; MAX over ranks (RCCL)."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        assert backend == "nccl" and dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def bench_train(args, rank, local_rank, world, backend):
     """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
     all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
     micro-batches, grad accumulation 2 like config.yaml:99), all-reduce, clip, Adam.  value = utterances/s over all ranks."""
@@ -101,46 +283,35 @@ def bench_train(args, rank, local_rank, world):
     sd = synth.make_state_dict(spec, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.cuda()
+    model.use_hip_kernels(args.train_kernels == "hip")
     bucket = FlatBucket(list(model.parameters()))
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
     U, L = args.utts, int(args.seconds * 16000)
     mix, clean = synth.synth_utterances(U, L, 3, seed=2000 + rank)
     mix, clean = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
-    on_gpu = world > 1 and dist.get_backend() == "nccl"
-    for _ in range(args.warmup):
-        train_step(model, bucket, opt, mix, clean, accum=2)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(model, bucket, opt, mix, clean, accum=2)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert np.isfinite(loss)
+    last = {}
+
+    def step():
+        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=2, loss=args.train_loss)
+
+    dt = timed_region(step, args.steps, args.warmup, world, backend)
+    assert np.isfinite(last["loss"])
     value = world * U * args.steps / dt
     result = dict(metric="DP training utterances/sec (TemporalCRN, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
                   steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
-                  vs_baseline=value / 1.09, dtype="f32", data="synthetic",
-                  config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, torch autograd forward/backward, "
-                                       "flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4; loss = SI-SNR term only (STOI unpinned)",
+                  vs_baseline=None, dtype="f32", data="synthetic",
+                  config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
+                                       f"loss = {args.train_loss}, flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
-                              baseline_note="vs_baseline divides by the reference's 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1) - indicative only"),
-                  roofline=None, cpu_baseline=None)
+                              reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
+                  roofline=model.train_roofline() if hasattr(model, "train_roofline") else None, cpu_baseline=None)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_fullsubnet(args, rank, local_rank, world):
+def bench_fullsubnet(args, rank, local_rank, world, backend):
     """BASELINE configs[2]: FullSubNet (fb + sb 2-layer LSTM) streaming inference, reference config.yaml:153-172."""
     import torch
     import torch.distributed as dist
@@ -152,36 +323,18 @@ def bench_fullsubnet(args, rank, local_rank, world):
     base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)
     mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
     out = torch.empty((B, L), dtype=torch.float32, device="cuda")
-    P, K = 1600, 3200
-    Lp = L + P
-    gap = K - (P + Lp % K) % K
-    nseg = 2 * (Lp + gap + P) // K
-    for _ in range(args.warmup):
-        eng.realtime_process(mix, out=out)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.realtime_process(mix, out=out)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    nseg = seg_count(L)
+    dt = timed_region(lambda: eng.realtime_process(mix, out=out), args.steps, args.warmup, world, backend)
     assert bool(torch.isfinite(out).all())
     value = world * B * nseg * args.steps / dt
     tf = value / world * eng.flops_per_frame / 1e12
-    result = dict(metric="streaming frames/sec @ b256 (FullSubNet, 3200-samp 16 kHz)", value=value, unit="frames/s", n_gpus=world,
+    result = dict(metric=f"streaming frames/sec @ b{B} (FullSubNet, 3200-samp 16 kHz)", value=value, unit="frames/s", n_gpus=world,
                   steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
                   vs_baseline=None, dtype="f32", data="synthetic",
                   config=dict(workload=f"FullSubNet realtime_process(train=False), batch {B} streams/GPU, 400-pt STFT / 201 bins, {args.seconds:g} s "
                                        f"utterances ({nseg} frames per stream), hash-generated weights", streams_per_gpu=B, frames_per_stream=nseg,
-                              realtime_factor=value * 0.1, mflop_per_frame=eng.flops_per_frame / 1e6),
+                              realtime_factor=value * 0.1, audio_realtime_factor=world * B * args.seconds * args.steps / dt,
+                              mflop_per_frame=eng.flops_per_frame / 1e6),
                   roofline=dict(bound="mfma", kernel="k_lstm_step_x6", achieved=tf, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
                                 frac=tf / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
                                 note="whole-path rate; the fused sub-band LSTM step GEMM holds 99 % of the FLOPs (bf16x6 MFMA, see DESIGN.md)"),
@@ -192,86 +345,26 @@ def bench_fullsubnet(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--nfft", type=int, default=512, help="512 = BASELINE.json configs[1]; 400 = reference config.yaml default")
-    ap.add_argument("--seconds", type=float, default=3.0, help="utterance length")
-    ap.add_argument("--model", choices=sorted(MODELS) + ["fullsubnet"], default="crn", help="crn = BASELINE.json headline (default)")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="train = BASELINE configs[3]: data-parallel training step (torch autograd + flat-bucket RCCL all-reduce)")
-    ap.add_argument("--utts", type=int, default=8, help="--mode train: utterances per GPU per optimizer step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
-                    help="f32 = fp32-accurate contractions (headline); f16 = fp16 MFMA operands, fp32 accumulate (BASELINE config 5: --model student --dtype f16 --batch 1024)")
-    args = ap.parse_args()
-
+def bench_crn(args, rank, local_rank, world, backend):
     import torch
     import torch.distributed as dist
     from speech_enhancement_mi_amd import engine, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(1, ndev)  # rehearsal with more ranks than GPUs shares devices (gloo, see below)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world <= ndev:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")  # several ranks per GPU: RCCL refuses duplicate devices
-
-    if args.mode == "train":
-        return bench_train(args, rank, local_rank, world)
-    if args.model == "fullsubnet":
-        return bench_fullsubnet(args, rank, local_rank, world)
     cfg = crn_cfg(args.nfft, args.model)
-    variant = MODELS[args.model][0]
+    variant, _, _, label = MODELS[args.model]
     spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=variant)
     sd = synth.make_state_dict(spec, seed=0)
     eng = engine.Engine(engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], 3200, 2, 3, 3, 16000, 25, 10, args.nfft,
-                                           variant=variant, precision=1 if args.dtype == "f16" else 0), local_rank)
+                                           variant=variant, precision=PRECISIONS[args.dtype]), local_rank)
     eng.load_state_dict(sd)
 
     B, L = args.batch, int(args.seconds * 16000)
     base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)  # 16 distinct utterances, tiled over the batch
     mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
     out = torch.empty((B, L), dtype=torch.float32, device="cuda")
-    P, K = 1600, 3200
-    Lp = L + P
-    gap = K - (P + Lp % K) % K
-    nseg = 2 * (Lp + gap + P) // K
+    nseg = seg_count(L)
 
-    on_gpu = world > 1 and dist.get_backend() == "nccl"
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        eng.realtime_process(mix, out=out)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.realtime_process(mix, out=out)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_region(lambda: eng.realtime_process(mix, out=out), args.steps, args.warmup, world, backend)
     assert bool(torch.isfinite(out).all()), "non-finite output"
-
     frames = world * B * nseg * args.steps
     value = frames / dt
 
@@ -289,14 +382,17 @@ def main():
     dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     d = by_kernel[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    # k_conv_x6 / k_gemm_bf16x6 produce fp32-accurate results from 6 bf16 MFMAs per product: `achieved`
-    # counts ALGORITHMIC fp32 FLOPs and is priced against the fp32 matrix peak, the peak of the dtype the path computes in;
-    # the bf16 matrix-core work actually executed is 6x that and is reported next to the bf16 dense peak.
-    x6 = dom in ("k_conv_x6", "k_gemm_bf16x6") and args.dtype == "f32"
-    peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else 2500.0  # fp16 operands: priced against the dense fp16 matrix peak
+    # The contraction kernels produce fp32-accurate results from split-bf16 MFMAs (6 products per MAC at precision f32, 3 at
+    # bf16x3): `achieved` counts ALGORITHMIC fp32 FLOPs and is priced against the fp32 matrix peak, the peak of
+    # the dtype the path computes in; the bf16 matrix-core work actually executed is reported next to the bf16 dense peak.
+    terms = {"f32": 6.0, "bf16x3": 3.0, "f16": 1.0}[args.dtype]
+    split = args.dtype in ("f32", "bf16x3")
+    peak = FP32_MATRIX_PEAK_TFLOPS if split else BF16_DENSE_PEAK_TFLOPS  # fp16 operands: priced against the dense fp16 matrix peak
+    workload_key = f"{args.model}/b{B}/nfft{args.nfft}/{args.dtype}"
+    traffic, traffic_note = pmc_traffic(dom, workload_key)
     roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s",
-                    frac=achieved / peak, traffic=pmc_traffic(dom, args) if args.dtype == "f32" else None,
-                    executed_bf16_tflops=(6.0 * achieved if x6 else None), bf16_dense_peak=(2500.0 if x6 else None),
+                    frac=achieved / peak, traffic=traffic, traffic_note=traffic_note,
+                    executed_bf16_tflops=(terms * achieved if split else None), bf16_dense_peak=(BF16_DENSE_PEAK_TFLOPS if split else None),
                     avg_launch_us=1e3 * d["ms"] / max(1, d["launches"]), launches_per_step=d["launches"],
                     flops_per_launch=d["flops"] / max(1, d["launches"]),
                     whole_path_tflops=value / world * eng.flops_per_frame / 1e12,
@@ -305,22 +401,68 @@ def main():
                              for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
                     labels={r["label"]: dict(ms=round(r["ms"], 3), launches=r["launches"]) for r in recs})
 
-    result = dict(metric="streaming frames/sec @ b256 (CRN, 3200-samp 16 kHz)", value=value, unit="frames/s",
+    tol_note = {"f32": "fp32-accurate (6-term split-bf16 MFMA), parity <= 1e-6 rel vs reference",
+                "bf16x3": "3-term split-bf16 MFMA (hi*hi + hi*mid + mid*hi), parity checked against the reference goldens at 1e-4 rel RMS / 0.02 dB",
+                "f16": "fp16 MFMA operands, fp32 accumulate: OUTSIDE north_star's 1e-4 / 0.02 dB parity bar (1.6e-3..2.6e-3 rel, <= 0.05 dB), reported for reference only"}[args.dtype]
+    result = dict(metric=f"streaming frames/sec @ b{B} ({label}, 3200-samp 16 kHz)", value=value, unit="frames/s",
                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                   config=dict(workload=f"TemporalCRN ({args.model}) realtime_process, batch {B} streams/GPU, {args.nfft}-pt STFT / {cfg['num_freqs']} bins, hop 160, "
                                        f"{args.seconds:g} s utterances ({nseg} frames of 3200 samples per stream), hash-generated weights",
                               streams_per_gpu=B, frames_per_stream=nseg, n_fft=args.nfft, parallelism=f"streams sharded x{world}, no collective",
-                              realtime_factor=value * 0.1, mflop_per_frame=eng.flops_per_frame / 1e6),
+                              realtime_factor=value * 0.1,  # SURVEY 8d definition: every frame (incl. the reference's pad / gap frames) = 100 ms
+                              audio_realtime_factor=world * B * args.seconds * args.steps / dt,  # real seconds of audio / wall second
+                              mflop_per_frame=eng.flops_per_frame / 1e6, precision=tol_note, collective_backend=backend),
                   roofline=roofline)
     if rank == 0:
+        result["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, sd, variant)
-        else:
-            result["cpu_baseline"] = None
+            if variant == 0:
+                result["cpu_baseline_torch"] = cpu_baseline_torch(cfg, sd)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--nfft", type=int, default=512, help="512 = BASELINE.json configs[1]; 400 = reference config.yaml default")
+    ap.add_argument("--seconds", type=float, default=3.0, help="utterance length")
+    ap.add_argument("--model", choices=sorted(MODELS) + ["fullsubnet"], default="crn", help="crn = BASELINE.json headline (default)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train = BASELINE configs[3]: data-parallel training step (flat-bucket RCCL all-reduce)")
+    ap.add_argument("--utts", type=int, default=8, help="--mode train: utterances per GPU per optimizer step")
+    ap.add_argument("--train-kernels", choices=["hip", "torch"], default="torch",
+                    help="--mode train: hip = hand-written forward/backward kernels for conv / transposed conv / GRU (default); torch = autograd checker path")
+    ap.add_argument("--train-loss", choices=["full", "sisnr"], default="sisnr",
+                    help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=sorted(PRECISIONS), default="f32",
+                    help="f32 = fp32-accurate contractions (headline); bf16x3 = 3-term split-bf16 (inside the 1e-4 parity bar; BASELINE config 5: "
+                         "--model student --dtype bf16x3 --batch 1024); f16 = fp16 MFMA operands (outside the parity bar)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the parent of N ranks BEFORE anything touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("SE_BENCH_SELFTEST") == "1":
+        return launcher_selftest(args)
+    rank, local_rank, world, backend = init_world(args)
+    if args.mode == "train":
+        return bench_train(args, rank, local_rank, world, backend)
+    if args.model == "fullsubnet":
+        return bench_fullsubnet(args, rank, local_rank, world, backend)
+    return bench_crn(args, rank, local_rank, world, backend)
 
 
 if __name__ == "__main__":

@@ -54,8 +54,10 @@ typedef struct {
                                            2 = distillation_crn.py TemporalCRN, the student architecture (as 1, but arctan
                                            phase and gLN denominator sqrt(var)+eps; distillation_crn.py:51,340) */
     int32_t precision;                  /* 0 = fp32-accurate contractions (6-term split-bf16 MFMA); 1 = fp16 MFMA operands with
-                                           fp32 accumulation for the convolutions and dense layers (the `.half()` / autocast
-                                           inference mode of BASELINE config 5).  Storage and the recurrence stay fp32. */
+                                           fp32 accumulation for the convolutions and dense layers (`model.half()`; OUTSIDE the
+                                           1e-4 parity bar: 2e-3 relative); 2 = 3-term split-bf16 (hi*hi + hi*mid + mid*hi, 16
+                                           mantissa bits per operand, fp32 accumulation: inside the 1e-4 / 0.02 dB bar, half the
+                                           matrix work of mode 0; the fast mode of BASELINE config 5).  The recurrence stays fp32. */
 } se_config;
 
 typedef struct se_engine se_engine;
@@ -98,7 +100,9 @@ int se_istft(se_engine *e, const float *spec, int n, float *wav, void *stream);
 int se_forward(se_engine *e, const float *x, float *y, void *stream);
 
 /* Debug taps of the last forward, converted to the reference's [B, C, F, T] layout, copied to HOST.
- * name: "feat" (encoder input, after the preconv blocks for variants 1/2), "enc0".."encN", "gru", "dec0".."decN".
+ * name: "feat" (encoder input, after the preconv blocks for variants 1/2), "enc0".."encN", "gru", "dec0".."decN";
+ * "ft0".."ftL": the pre-activation feature maps the distillation student returns (distillation_crn.py:467-477): last encoder
+ * convolution [B, C, F, T], fc_output_layer output ([B, T, D] memory), transposed-convolution outputs of decoder blocks 0..L-2.
  * Synchronises the stream.  *count = elements. */
 int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
 
@@ -121,6 +125,10 @@ int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap,
                     int64_t *launches, double *flops_per_launch);
 
 int se_abi_version(void);
+/* sizeof(se_config) / sizeof(fsn_config) as this library was built: a binding checks its own struct mirror against these
+ * before the first se_create (a short struct would leave `precision` reading whatever follows it). */
+int se_config_size(void);
+int fsn_config_size(void);
 
 /* ---- FullSubNet (reference fullsubnet.py:685-961; BASELINE config 3) -------------------
  * Same conventions as the se_* calls above.  Checkpoint keys: fb_model.* / sb_model.* of FullSubNet.state_dict(). */

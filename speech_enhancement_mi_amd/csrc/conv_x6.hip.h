@@ -19,19 +19,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hip.h"
-#include "gemm.hip.h"
+#include "split_bf16.h"
 
 namespace se {
-
-constexpr int kX6PosPerThread = 4;  // (patch position, octet) items per thread: CO*R*St <= 1024 (host-checked)
-
-struct ConvX6Args {
-    ConvArgs c;        // geometry, x / xprev / bias / y / stats exactly as for k_conv_igemm (c.w unused, c.CC == 8)
-    const uint4 *wx;   // [nchunk][nstep][3][MT][64] fragments of 16 B
-#ifdef SE_X6_TRACE
-    int trace_slot;
-#endif
-};
 
 __device__ __forceinline__ uint4 pack_bf16x8(const __bf16 (&v)[8]) {
     bf16x8 t;
@@ -49,7 +39,9 @@ __device__ unsigned long long g_x6_trace[16];
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// PL = operand planes: 3 = fp32-accurate bf16x6 (six cross terms per product); 1 = plain fp16 operands with fp32
+// PL = operand planes: 3 = fp32-accurate bf16x6 (six cross terms per product); 2 = bf16x3 (hi, mid planes; three cross terms
+// hi*hi + hi*mid + mid*hi: 16 mantissa bits per operand, measured 4e-6 relative on a K = 1664 GEMM, se_config.precision = 2);
+// 1 = plain fp16 operands with fp32
 // accumulation (se_config.precision = 1: the fp16 inference mode of BASELINE config 5, 6x fewer MFMAs, a third of the LDS
 // traffic; operands rounded to 11 mantissa bits)
 template <int NTAP, int NT, int CO, int PL>
@@ -168,13 +160,13 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
             if (item < CO * Npos) {
                 const bool ok = (okmask >> k) & 1u;
                 const int cbase = ch * 8 * CO + (CO > 1 ? (int)((octs >> (2 * k)) & 3u) * 8 : 0);
-                if (PL == 3) {
+                if (PL >= 2) {
                     __bf16 h[8], m[8], l[8];
 #pragma unroll
                     for (int c = 0; c < 8; c++) split3((ok && cbase + c < a.Ci) ? pv[k][c] : 0.0f, h[c], m[c], l[c]);
                     planes[item] = pack_bf16x8(h);
                     planes[CO * Npos + item] = pack_bf16x8(m);
-                    planes[2 * CO * Npos + item] = pack_bf16x8(l);
+                    if (PL == 3) planes[2 * CO * Npos + item] = pack_bf16x8(l);
                 } else {
                     f16x8 hv;
 #pragma unroll
@@ -210,15 +202,17 @@ __global__ __launch_bounds__(256, NT <= 2 ? 3 : 2) void k_conv_x6(ConvX6Args xa)
             for (int i = 0; i < NT; i++) {
                 const int pos = lane_base[i] + toffL[pr];
                 f32x16 c = acc[i];
-                if (PL == 3) {
+                if (PL >= 2) {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[0]), a1 = __builtin_bit_cast(bf16x8, fa[PL > 1 ? 1 : 0]),
                                  a2 = __builtin_bit_cast(bf16x8, fa[PL > 2 ? 2 : 0]);
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
                     const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[CO * Npos + pos]);
-                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                    if (PL == 3) {
+                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);  // hi*mid
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);  // mid*hi
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);  // hi*hi

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hip.h"
+#include "split_bf16.h"
 
 namespace se {
 
@@ -115,8 +116,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn(GemmArgs a) {
 // fp32 MFMAs (8 x 64 cycles): 2.7x fewer matrix-pipe cycles, which is what bounds this path (and the chip holds
 // a low clock under sustained fp32 MFMA load).
 // W is pre-split on the host (three [N][K] bf16 planes); A is split on the fly while it is staged into LDS.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kXLd = kGemmKC + 8;  // bf16 elements per LDS row (80 B: conflict-free 16-B fragment reads)
 
 struct GemmX6Args {
@@ -129,18 +128,12 @@ struct GemmX6Args {
     int relu;
 };
 
-__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    l = (__bf16)r2;
-}
 
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4g __attribute__((ext_vector_type(4)));
 
-// PL = operand planes: 3 = bf16x6 (fp32-accurate), 1 = fp16 operands (se_config.precision = 1); Wp then holds ONE fp16 plane
+// PL = operand planes: 3 = bf16x6 (fp32-accurate), 2 = bf16x3 (hi, mid planes; se_config.precision = 2), 1 = fp16 operands
+// (se_config.precision = 1); Wp then holds PL planes [PL][N][K]
 template <int PL>
 __global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
     __shared__ __align__(16) __bf16 Ap[PL][kGemmBM * kXLd];
@@ -180,7 +173,7 @@ __global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
         for (int it = 0; it < 4; it++) {
             const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
             const bool ok = (m0 + r < a.M) && (k0 + kq < a.K);
-            if (PL == 3) {
+            if (PL >= 2) {
                 bf16x4 h, m, l;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -190,7 +183,7 @@ __global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
                 }
                 *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
                 *reinterpret_cast<bf16x4 *>(&Ap[PL > 1 ? 1 : 0][r * kXLd + kq]) = m;
-                *reinterpret_cast<bf16x4 *>(&Ap[PL > 2 ? 2 : 0][r * kXLd + kq]) = l;
+                if (PL == 3) *reinterpret_cast<bf16x4 *>(&Ap[PL > 2 ? 2 : 0][r * kXLd + kq]) = l;
             } else {
                 f16x4g h;
 #pragma unroll
@@ -221,14 +214,16 @@ __global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     f32x16 c = acc[i][j];
-                    if (PL == 3) {
+                    if (PL >= 2) {
                         const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][PL > 1 ? 1 : 0]),
                                      a2 = __builtin_bit_cast(bf16x8, fa[i][PL > 2 ? 2 : 0]);
                         const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][PL > 1 ? 1 : 0]),
                                      b2 = __builtin_bit_cast(bf16x8, fb[j][PL > 2 ? 2 : 0]);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                        if (PL == 3) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
+                        }
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);  // hi*mid
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);  // mid*hi
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);  // hi*hi

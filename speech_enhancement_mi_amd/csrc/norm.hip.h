@@ -63,7 +63,7 @@ struct FeatArgs {
     int atan2_phase;  // 0: arctan(im/(re+eps)+eps) (CRN.py:464, distillation_crn.py:340); 1: atan2(im, re) (CRN_ELU.py:370)
 };
 
-#ifndef SE_AUX_KERNELS
+#if !defined(SE_AUX_KERNELS) && !defined(SE_NO_NORM_KERNELS)
 __global__ void k_featurize(FeatArgs a) {
     const int b = blockIdx.y;
     const int TF = a.T * a.F;
@@ -82,7 +82,7 @@ __global__ void k_featurize(FeatArgs a) {
     }
 }
 
-#endif  // !SE_AUX_KERNELS
+#endif  // norm kernels
 
 // ---- gLN with optional re-layout ---------------------------------------------------------------
 struct GlnArgs {
@@ -96,7 +96,7 @@ struct GlnArgs {
     int eps_mode;
 };
 
-#ifndef SE_AUX_KERNELS
+#if !defined(SE_AUX_KERNELS) && !defined(SE_NO_NORM_KERNELS)
 __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
     __shared__ double red[16];
     const float *x = a.x + (long)blockIdx.x * a.n;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_gln(GlnArgs a) {
     }
 }
 
-#endif  // !SE_AUX_KERNELS
+#endif  // norm kernels
 
 // ---- cIRM decompression (utility.py:439-442) --------------------------------------------------------------
 __device__ inline float decompress_cirm(float m) {
@@ -167,7 +167,7 @@ struct GlnEwArgs {
 
 // VW = 4: float4 path (n % 4 == 0, so every stream's base stays 16-B aligned); VW = 1: scalar path for odd sizes
 // (the 5-channel preconv tensors of CRN_ELU: 5*21*201 elements).
-#ifndef SE_AUX_KERNELS
+#if !defined(SE_AUX_KERNELS) && !defined(SE_NO_NORM_KERNELS)
 template <int VW>
 __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     __shared__ float sm[2];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
     }
 }
 
-#endif  // !SE_AUX_KERNELS
+#endif  // norm kernels
 
 struct BlendEwArgs {
     const float *y, *uv;
@@ -226,7 +226,7 @@ struct BlendEwArgs {
     int Co, T, Fo, Fr;
 };
 
-#ifndef SE_AUX_KERNELS
+#if !defined(SE_AUX_KERNELS) && !defined(SE_NO_NORM_KERNELS)
 __global__ __launch_bounds__(256) void k_dec_blend_ew(BlendEwArgs a) {
     __shared__ float sm[4];
     const int b = blockIdx.y;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_dec_blend_ew(BlendEwArgs a) {
     }
 }
 
-#endif  // !SE_AUX_KERNELS
+#endif  // norm kernels
 
 struct MaskEwArgs {
     const float *y;

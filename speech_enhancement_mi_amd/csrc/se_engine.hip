@@ -23,8 +23,7 @@
 #include <vector>
 
 #include "../../include/se_engine.h"
-#include "conv_igemm.hip.h"
-#include "conv_x6.hip.h"
+#include "conv_dispatch.h"
 #include "fsn.hip.h"
 #include "fft_lds.h"
 #include "gemm.hip.h"
@@ -102,7 +101,7 @@ struct se_engine {
     DevBuf wih_x[4], fcw_x;  // bf16x3 planes [3][N][K] of the GEMM weights (k_gemm_bf16x6)
     int gemm_mode = 6;        // SE_GEMM_MODE: 0 = fp32 MFMA (k_gemm_tn), 6 = bf16x6 (default)
     int variant = 0, act = 1, eps_mode = 0, atan2_phase = 0, npre = 0;  // derived from se_config.variant
-    int precision = 0;        // se_config.precision: 0 = bf16x6 (3 operand planes), 1 = fp16 operands (1 plane)
+    int precision = 0;        // se_config.precision: 0 = bf16x6 (3 operand planes), 1 = fp16 operands (1 plane), 2 = bf16x3 (2 planes)
     int num_cu = 256;         // compute units of the device (MI355X: 256)
     int dec_merge = 1;        // SE_DEC_MERGE=0: narrow decoder blocks as two parity launches like the wide ones
     int skip_fuse = 1;        // SE_SKIP_FUSE=0: skip convolution writes both tensors, k_dec_blend_ew applies the gate
@@ -232,7 +231,11 @@ float bf16_to_f32(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
-// three bf16 planes (hi, mid, lo) of a [rows][cols] fp32 matrix -> device buffer of 3*rows*cols uint16
+// operand planes per precision mode: 0 -> 3 bf16 planes (hi, mid, lo; six products), 1 -> 1 fp16 plane, 2 -> 2 bf16 planes
+// (hi, mid; three products hi*hi + hi*mid + mid*hi)
+inline int operand_planes(int precision) { return precision == 1 ? 1 : (precision == 2 ? 2 : 3); }
+
+// bf16 planes (hi, mid, lo) of a [rows][cols] fp32 matrix -> device buffer of PL*rows*cols uint16
 int upload_split3(se_engine *e, DevBuf &b, const std::vector<float> &w) {
     const size_t n = w.size();
     if (e->precision == 1) {  // one fp16 plane
@@ -243,16 +246,18 @@ int upload_split3(se_engine *e, DevBuf &b, const std::vector<float> &w) {
         HIPCHECK(e, hipMemcpy(b.p, plane.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
         return 0;
     }
-    std::vector<uint16_t> planes(3 * n);
+    const int PL = operand_planes(e->precision);
+    std::vector<uint16_t> planes(PL * n);
     for (size_t i = 0; i < n; i++) {
         const float x = w[i];
         const uint16_t h = bf16_rne(x);
         const float r1 = x - bf16_to_f32(h);
         const uint16_t m = bf16_rne(r1);
         const float r2 = r1 - bf16_to_f32(m);
-        planes[i] = h; planes[n + i] = m; planes[2 * n + i] = bf16_rne(r2);
+        planes[i] = h; planes[n + i] = m;
+        if (PL > 2) planes[2 * n + i] = bf16_rne(r2);
     }
-    int rc = dev_alloc(e, b, (3 * n + 1) / 2);
+    int rc = dev_alloc(e, b, (PL * n + 1) / 2);
     if (rc) return rc;
     HIPCHECK(e, hipMemcpy(b.p, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return 0;
@@ -342,7 +347,7 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
                 if ((size_t)CO * c_Rmax * St > 256 * kX6PosPerThread) continue;
                 ConvPlan::Geo &g = pl.geo[c_NT - 1];
                 g.NT = c_NT; g.tpw = c_tpw; g.n_wg = c_wg; g.grouped = c_grouped;
-                g.lds = std::max<size_t>((size_t)(e->precision == 1 ? 1 : 3) * CO * c_Rmax * St * 16, 64);
+                g.lds = std::max<size_t>((size_t)operand_planes(e->precision) * CO * c_Rmax * St * 16, 64);
                 tpw = c_tpw; n_wg = c_wg; NT = c_NT; Rmax = c_Rmax; grouped = c_grouped;
             }
             if (NT > 0) break;
@@ -356,10 +361,10 @@ int plan_conv(se_engine *e, ConvPlan &pl, int Ci, int Co, int FP, int Fi, int Fy
             a.relu_lo = relu_lo; a.relu_hi = relu_hi; a.act = act; a.gate_pairs = gate_pairs; a.Cy = Cy; a.cy0 = cy0;
             for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
             pl.NT = NT; pl.grid_x = n_wg; pl.x6 = true; pl.CO = CO;
-            pl.lds = std::max<size_t>((size_t)(e->precision == 1 ? 1 : 3) * CO * Rmax * St * 16, 64);
+            pl.lds = std::max<size_t>((size_t)operand_planes(e->precision) * CO * Rmax * St * 16, 64);
             // weights: [chunk][step][plane][mtile][co 32][k 16], k = half*8 + c <-> entry 2*step+half = (tap, octet) tap-major,
             // channel chunk*8*CO + octet*8 + c
-            const int PL = e->precision == 1 ? 1 : 3;
+            const int PL = operand_planes(e->precision);
             std::vector<uint16_t> wx((size_t)nchunk * nstep * PL * MT * 32 * 16, 0);
             for (int ch = 0; ch < nchunk; ch++)
                 for (int st = 0; st < nstep; st++)
@@ -670,34 +675,13 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
 #ifdef SE_X6_TRACE
         { const char *want = getenv("SE_X6_TRACE_LABEL"); xa.trace_slot = (want && label && strcmp(want, label) == 0) ? 0 : -1; }
 #endif
-#define SE_X6_CASE(NTAP_, NT_, CO_) \
-    case (NTAP_ * 8 + NT_) * 8 + CO_: \
-        if (e->precision == 1) hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_, 1>), grid, dim3(256), pl.lds, st, xa); \
-        else hipLaunchKernelGGL((k_conv_x6<NTAP_, NT_, CO_, 3>), grid, dim3(256), pl.lds, st, xa); \
-        break;
-#define SE_X6_TAPS(NTAP_, CO_) SE_X6_CASE(NTAP_, 1, CO_) SE_X6_CASE(NTAP_, 2, CO_) SE_X6_CASE(NTAP_, 3, CO_) SE_X6_CASE(NTAP_, 4, CO_)
-        switch ((a.ntap * 8 + pl.NT) * 8 + pl.CO) {
-            SE_X6_TAPS(15, 1) SE_X6_TAPS(9, 1) SE_X6_TAPS(6, 1) SE_X6_TAPS(1, 1) SE_X6_TAPS(1, 2) SE_X6_TAPS(1, 4)
-            default: return fail(e, SE_ERR_ARG, "no x6 conv kernel instance for %d taps x %d tiles x %d octets", a.ntap, pl.NT, pl.CO);
-        }
-#undef SE_X6_TAPS
-#undef SE_X6_CASE
+        if (conv_x6_launch(a.ntap, pl.NT, pl.CO, operand_planes(e->precision), grid, pl.lds, st, xa))
+            return fail(e, SE_ERR_ARG, "no x6 conv kernel instance for %d taps x %d tiles x %d octets", a.ntap, pl.NT, pl.CO);
         HIPCHECK(e, hipGetLastError());
         return 0;
     }
-#define SE_CONV_CASE(NTAP_, NT_) \
-    case NTAP_ * 8 + NT_: hipLaunchKernelGGL((k_conv_igemm<NTAP_, NT_>), grid, dim3(256), pl.lds, st, a); break;
-#define SE_CONV_TAPS(NTAP_) SE_CONV_CASE(NTAP_, 1) SE_CONV_CASE(NTAP_, 2) SE_CONV_CASE(NTAP_, 3) SE_CONV_CASE(NTAP_, 4) \
-    case NTAP_ * 8: if (a.CoPad == 4) hipLaunchKernelGGL((k_conv_small<NTAP_, 1>), grid, dim3(256), pl.lds, st, a); \
-                    else if (a.CoPad == 8) hipLaunchKernelGGL((k_conv_small<NTAP_, 2>), grid, dim3(256), pl.lds, st, a); \
-                    else hipLaunchKernelGGL((k_conv_small<NTAP_, 4>), grid, dim3(256), pl.lds, st, a); break;
-    switch (a.ntap * 8 + pl.NT) {
-        SE_CONV_TAPS(15) SE_CONV_TAPS(9) SE_CONV_TAPS(6) SE_CONV_TAPS(1)
-        case 25 * 8: hipLaunchKernelGGL((k_conv_small<25, 2>), grid, dim3(256), pl.lds, st, a); break;
-        default: return fail(e, SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
-    }
-#undef SE_CONV_TAPS
-#undef SE_CONV_CASE
+    if (conv_igemm_launch(a.ntap, pl.NT, a.CoPad, grid, pl.lds, st, a))
+        return fail(e, SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, pl.NT);
     HIPCHECK(e, hipGetLastError());
     return 0;
 }
@@ -706,9 +690,10 @@ int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw
                 int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label, const float *Wx = nullptr) {
     dim3 ggrid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
     if (Wx && e->gemm_mode == 6 && Kd % 8 == 0 && Kd >= 8 && lda % 4 == 0 && ldw == Kd) {
-        ProfScope ps(e, e->precision == 1 ? "k_gemm_f16" : "k_gemm_bf16x6", label, 2.0 * Mr * Nc * Kd, st);
+        ProfScope ps(e, e->precision == 1 ? "k_gemm_f16" : (e->precision == 2 ? "k_gemm_bf16x3" : "k_gemm_bf16x6"), label, 2.0 * Mr * Nc * Kd, st);
         GemmX6Args g{A, reinterpret_cast<const __bf16 *>(Wx), bias, C, Mr, Nc, Kd, lda, ldc, relu};
         if (e->precision == 1) hipLaunchKernelGGL(k_gemm_x<1>, ggrid, dim3(256), 0, st, g);
+        else if (e->precision == 2) hipLaunchKernelGGL(k_gemm_x<2>, ggrid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL(k_gemm_x<3>, ggrid, dim3(256), 0, st, g);
         HIPCHECK(e, hipGetLastError());
         return 0;
@@ -950,7 +935,10 @@ int ensure_ready(se_engine *e) {
 
 extern "C" {
 
-int se_abi_version(void) { return 2; }
+int se_abi_version(void) { return 3; }
+
+int se_config_size(void) { return (int)sizeof(se_config); }
+int fsn_config_size(void) { return (int)sizeof(fsn_config); }
 
 const char *se_last_error(const se_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -973,7 +961,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     e->device = device;
     e->L = L; e->M = cfg->num_inputs; e->K = cfg->segment_length; e->N = cfg->n_fft; e->H = cfg->hidden; e->NL = cfg->num_layers;
     if (cfg->variant < 0 || cfg->variant > 2) { delete e; return fail(nullptr, SE_ERR_ARG, "variant %d unknown (0 CRN, 1 CRN_ELU, 2 student)", cfg->variant); }
-    if (cfg->precision < 0 || cfg->precision > 1) { delete e; return fail(nullptr, SE_ERR_ARG, "precision %d unknown (0 fp32-accurate, 1 fp16 operands)", cfg->precision); }
+    if (cfg->precision < 0 || cfg->precision > 2) { delete e; return fail(nullptr, SE_ERR_ARG, "precision %d unknown (0 fp32-accurate, 1 fp16 operands, 2 bf16x3)", cfg->precision); }
     e->precision = cfg->precision;
     e->variant = cfg->variant;
     e->act = cfg->variant ? 2 : 1;
@@ -1024,21 +1012,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     }
     // opt in to large dynamic LDS for the FFT kernels
     aux_set_fft_lds((int)stft_lds_bytes(K, N), (int)istft_lds_bytes(T, N));
-#define SE_CONV_ATTR(NTAP_)                                                                                                        \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_igemm<NTAP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_small<NTAP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SE_CONV_ATTR(15) SE_CONV_ATTR(9) SE_CONV_ATTR(6) SE_CONV_ATTR(1)
-#undef SE_CONV_ATTR
-#define SE_X6_ATTR(NTAP_, CO_)                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 1, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 2, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 3, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_x6<NTAP_, 4, CO_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SE_X6_ATTR(15, 1) SE_X6_ATTR(9, 1) SE_X6_ATTR(6, 1) SE_X6_ATTR(1, 1) SE_X6_ATTR(1, 2) SE_X6_ATTR(1, 4)
-#undef SE_X6_ATTR
+    conv_set_attributes();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
@@ -1051,17 +1025,7 @@ void se_destroy(se_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
-#ifdef SE_X6_TRACE
-    {
-        unsigned long long t[16] = {0};
-        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_x6_trace), sizeof(t));
-        if (t[15]) {
-            const char *nm[9] = {"prologue + pair loops", "barrier1", "wait staging loads", "split+lds write", "barrier2", "first A frag", "epilogue issue", "epilogue store drain", "stats reduce"};
-            fprintf(stderr, "[x6 trace %s] %llu WG-samples\n", getenv("SE_X6_TRACE_LABEL"), t[15]);
-            for (int i = 0; i < 9; i++) fprintf(stderr, "   %-28s %10.0f cycles/WG\n", nm[i], (double)t[i] / t[15]);
-        }
-    }
-#endif
+    conv_x6_trace_dump();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->maskspec,
                          &e->gru_sync, &e->fcw_x, &e->pre_g, &e->spec_all, &e->mask_all, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
@@ -1532,6 +1496,55 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
     } else if (sscanf(name, "dec%d", &idx) == 1 && idx >= 0 && idx < L - 1) {
         const int lvl = L - 1 - idx;
         src = e->dec_out[idx].p; C = e->Ch[lvl]; F = e->F[lvl];
+    } else if (sscanf(name, "ft%d", &idx) == 1 && idx >= 0 && idx <= L) {
+        // Pre-activation feature maps of the distillation student (distillation_crn.py:222-228, 126-128, 262-264, 467-477):
+        // ft0 = last encoder block's convolution output, ft1 = fc_output_layer output ([B, T, D] memory viewed as [B, C, F, T],
+        // distillation_crn.py:364), ft2.. = transposed-convolution outputs of decoder blocks 0..L-2 (before activation, norm and
+        // frequency padding).  The hot path fuses the activation into the producing kernel, so the tap RE-RUNS that one kernel
+        // without activation on the inputs still held in the ring slot; nothing on the inference path pays for it.
+        const int prev = (cur + kRing - 1) % kRing;
+        int rc = ensure_ready(e);
+        if (rc) return rc;
+        DevBuf tmp;
+        auto finish = [&](int C_, int F_, bool raw_flat) -> int {
+            const size_t n_ = (size_t)B * C_ * T * F_;
+            if (count) *count = (int64_t)n_;
+            if ((int64_t)n_ > capacity) { dev_free(tmp); return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n_); }
+            std::vector<float> h(n_);
+            hipError_t st1 = hipStreamSynchronize(st), st2 = hipMemcpy(h.data(), tmp.p, n_ * sizeof(float), hipMemcpyDeviceToHost);
+            dev_free(tmp);
+            if (st1 != hipSuccess || st2 != hipSuccess) return fail(e, SE_ERR_HIP, "tap copy failed");
+            if (raw_flat) { memcpy(host_out, h.data(), n_ * sizeof(float)); return SE_OK; }
+            for (int b = 0; b < B; b++)
+                for (int c = 0; c < C_; c++)
+                    for (int t = 0; t < T; t++)
+                        for (int f = 0; f < F_; f++) host_out[(((size_t)b * C_ + c) * F_ + f) * T + t] = h[(((size_t)b * C_ + c) * T + t) * F_ + f];
+            return SE_OK;
+        };
+        if (idx == 0) {
+            const int i = L - 1, Co = e->Ch[L], Fo = e->F[L];
+            if ((rc = dev_alloc(e, tmp, (size_t)B * Co * T * Fo))) return rc;
+            ConvPlan pl = e->lv[i].enc;
+            pl.a.relu_lo = pl.a.relu_hi = 0;
+            if ((rc = launch_conv(e, pl, e->xin[i][cur].p, e->xin[i][prev].p, tmp.p, st, "tap_ft"))) { dev_free(tmp); return rc; }
+            return finish(Co, Fo, false);
+        }
+        if (idx == 1) {
+            const int D = e->D, H = e->H;
+            if ((rc = dev_alloc(e, tmp, (size_t)B * T * D))) return rc;
+            if ((rc = launch_gemm(e, e->seq[(e->NL - 1) & 1].p, H, e->fcw.p, H, e->fcb.p, tmp.p, D, B * T, D, H, 0, st, "tap_ft", e->fcw_x.p))) { dev_free(tmp); return rc; }
+            return finish(e->Ch[L], e->F[L], true);
+        }
+        const int j = idx - 2, lvl = L - 1 - j;
+        if (lvl <= 0) return fail(e, SE_ERR_KEY, "unknown tap %s", name);
+        const int Co = e->Ch[lvl], Fo = 2 * e->F[lvl + 1] - 1;
+        if ((rc = dev_alloc(e, tmp, (size_t)B * Co * T * Fo))) return rc;
+        const float *xin = j == 0 ? e->dec_in[cur].p : e->dec_out[j - 1].p;
+        ConvPlan pe = e->lv[j].dec_even, po = e->lv[j].dec_odd;
+        pe.a.relu_lo = pe.a.relu_hi = 0;
+        po.a.relu_lo = po.a.relu_hi = 0;
+        if ((rc = launch_conv(e, pe, xin, nullptr, tmp.p, st, "tap_ft")) || (rc = launch_conv(e, po, xin, nullptr, tmp.p, st, "tap_ft"))) { dev_free(tmp); return rc; }
+        return finish(Co, Fo, false);
     } else return fail(e, SE_ERR_KEY, "unknown tap %s", name);
     const size_t n = (size_t)B * C * T * F;
     if (count) *count = (int64_t)n;

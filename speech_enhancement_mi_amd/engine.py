@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libse_engine.so")
 SE_MAX_LEVELS = 8
 
 EXPORTS = [
-    "se_abi_version", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_reset_stream", "se_step",
+    "se_abi_version", "se_config_size", "fsn_config_size", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_reset_stream", "se_step",
     "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
@@ -53,6 +53,10 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp, fp, i64p = C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
     L.se_abi_version.restype = C.c_int
+    # a struct mirror shorter than the library's se_config would leave its tail fields (precision) reading garbage
+    if L.se_config_size() != C.sizeof(SeConfig) or L.fsn_config_size() != C.sizeof(FsnConfig):
+        raise RuntimeError(f"libse_engine.so was built with sizeof(se_config) = {L.se_config_size()}, sizeof(fsn_config) = "
+                           f"{L.fsn_config_size()}; this binding has {C.sizeof(SeConfig)} / {C.sizeof(FsnConfig)}: rebuild the library")
     L.se_create.argtypes = [C.POINTER(SeConfig), C.c_int, C.POINTER(vp)]
     L.se_destroy.argtypes = [vp]
     L.se_destroy.restype = None
@@ -104,7 +108,7 @@ def make_config(num_channels, num_freqs, hidden, segment_length, num_layers=1, n
     cfg.hop = int(round(sample_rate / 1000.0 * hop_length))
     cfg.segment_length = int(segment_length)
     cfg.variant = int(variant)
-    cfg.precision = int(precision)  # 0 = fp32-accurate contractions, 1 = fp16 MFMA operands (model.half())
+    cfg.precision = int(precision)  # 0 = fp32-accurate (bf16x6), 1 = fp16 MFMA operands (model.half()), 2 = bf16x3 (set_precision)
     return cfg
 
 

@@ -66,6 +66,10 @@ class FullSubNet(nn.Module):
     def realtime_process(self, mixture, source=None, flag=False, train=True):
         # train=True in the reference runs one forward over all N*T frames of the chunk for back-propagation
         # (fullsubnet.py:921-927); both reference trainers and predict call train=False, which is what the engine implements
+        if train:
+            raise NotImplementedError("FullSubNet.realtime_process(train=True) - one forward over all N*T frames for back-propagation "
+                                      "(fullsubnet.py:921-927) - is not built; both reference trainers and predict_fullsubnet.py call "
+                                      "train=False (train_fullsubnet.py:138,151; predict_fullsubnet.py:75)")
         eng = self._engine_for(mixture)
         pred = eng.realtime_process(mixture.contiguous().float(), flag=bool(flag))
         return pred if source is None else (pred, None, None, None)

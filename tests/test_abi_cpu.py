@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in se_engine.h but not exported by libse_engine.so"
     assert sorted(engine.EXPORTS) == names
-    assert lib.se_abi_version() == 2
+    assert lib.se_abi_version() == 3
 
 
 def test_no_cpu_fallback():
@@ -35,3 +35,16 @@ def test_no_cpu_fallback():
     cfg = engine.make_config([4, 8, 8, 8], 201, 16, 3200, num_layers=2)
     with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback|se_create failed"):
         engine.Engine(cfg)
+
+
+def test_config_struct_sizes():
+    """INTEGRATION.md's ctypes mirror of se_config must have the library's size (a short struct would leave `precision`
+    reading whatever follows it): the library exports its own sizeof for the binding to check."""
+    from speech_enhancement_mi_amd import engine
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    assert lib.se_config_size() == ctypes.sizeof(engine.SeConfig)
+    assert lib.fsn_config_size() == ctypes.sizeof(engine.FsnConfig)
+    # the stub printed in INTEGRATION.md lists the same fields
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, _ in engine.SeConfig._fields_:
+        assert f'"{name}"' in text, f"INTEGRATION.md SeConfig stub lacks field {name}"

@@ -391,6 +391,7 @@ def test_variant_dropin_classes(vgolden):
     m2 = distillation_crn.TemporalCRN(**STUDENT400)
     assert abs(sum(p.numel() for p in m2.parameters()) / 1e6 - 0.812) < 0.005  # README.md:58 "0.81 MB"
     m2.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of_variant(STUDENT400, 2)).items()}, strict=True)
+    m2.return_features = False  # inference: skip the distillation feature taps (covered by tests/test_gpu_round2.py)
     y2, feats = m2.cuda().realtime_process(mt, flag=False)  # predict_distillation.py:84 unpacks a pair
     assert feats is None
     assert rel_rms(y2.cpu().numpy(), vgolden["student_full400_out"]) < TOL
@@ -520,6 +521,7 @@ def test_half_model_selects_fp16_engine():
     sd = synth.make_state_dict(spec_of_variant(STUDENT400, 2), seed=9)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.cuda()
+    m.return_features = False
     mix, _ = synth.synth_utterances(2, 8000, 3, seed=52)
     y32 = m.realtime_process(_cuda(mix))
     y32 = (y32[0] if isinstance(y32, tuple) else y32).float().cpu().numpy()

@@ -1,0 +1,179 @@
+"""GPU parity tests added in round 2 (VERDICT r01 'what's weak' 1-3, 'missing' 4-6): state hand-over through
+se_import_state, the student's distillation feature taps, FullSubNet at B = 256, the 3-term split-bf16 mode against the
+REFERENCE goldens at north_star's tolerance, and B = 1024 (BASELINE config 5)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FSN_FULL, FULL400, FULL512, STUDENT400, TINY, fsn_spec, rel_rms, spec_of, spec_of_variant
+from speech_enhancement_mi_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4       # north_star: waveforms within 1e-4 RMS of the reference CPU path (relative form, see test_gpu_parity.py)
+TOL_DB = 0.02    # north_star: SI-SDR within +-0.02 dB
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _engine(cfg, variant=0, precision=0, seed=0):
+    from speech_enhancement_mi_amd import engine
+    c = engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["segment_length"], cfg["num_layers"],
+                           cfg["num_inputs"], cfg["kernel_size"], cfg["sample_rate"], cfg["win_length"], cfg["hop_length"], cfg["n_fft"],
+                           variant=variant, precision=precision)
+    e = engine.Engine(c, 0)
+    e.load_state_dict(synth.make_state_dict(spec_of_variant(cfg, variant), seed=seed))
+    return e
+
+
+# ---- 8f-3: state hand-over -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,variant", [(FULL400, 0), (TINY, 1)])
+def test_import_state_into_fresh_engine(cfg, variant):
+    """Export every state tensor of engine A after 3 windows, import into a freshly reset engine B: the next window is
+    bit-equal (CRN.py:568-575 carried state: conv time buffers + GRU h; the variants add the preconv buffers).  Then one
+    stream of A moves into batch slot 0 of a 1-stream engine C (a caller changes servers): same output within rounding."""
+    B, L = 2, len(cfg["num_channels"])
+    a, b, c = (_engine(cfg, variant, seed=3) for _ in range(3))
+    mix, _ = synth.synth_utterances(B, 3200 * 4, 3, seed=61)
+    a.reset(B)
+    for k in range(3):
+        a.step(_cuda(mix[:, :, 3200 * k:3200 * (k + 1)]))
+    names = ["h"] + [f"buf{i}" for i in range(L)] + ([f"pbuf{i}" for i in range(3)] if variant else [])
+    state = {n: a.export_state(n) for n in names}
+    b.reset(B)
+    for n in names:
+        b.import_state(n, state[n])
+    w = _cuda(mix[:, :, 3200 * 3:3200 * 4])
+    ya, yb = a.step(w).cpu().numpy(), b.step(w).cpu().numpy()
+    assert np.array_equal(ya, yb)
+    for n in names:  # and the states after that window agree too
+        assert np.array_equal(a.export_state(n), b.export_state(n)), n
+    # stream 1 of the 2-stream batch -> slot 0 of a 1-stream engine
+    c.reset(1)
+    H = cfg["hidden"]
+    for n in names:
+        v = state[n]
+        one = v.reshape(cfg["num_layers"], B, H)[:, 1:2] if n == "h" else v.reshape(B, -1)[1:2]
+        c.import_state(n, np.ascontiguousarray(one))
+    yc = c.step(_cuda(mix[1:2, :, 3200 * 3:3200 * 4])).cpu().numpy()
+    assert rel_rms(yc[0], ya[1]) < 2e-6
+    with pytest.raises(RuntimeError, match="needs"):
+        c.import_state("h", np.zeros(3, np.float32))
+
+
+# ---- a13: the student's distillation feature taps -----------------------------------------------------------------------
+def test_student_feature_taps_golden(vgolden):
+    """distillation_crn.TemporalCRN.realtime_process returns (pred, [5 pre-activation feature maps of [N*B, C, F, T]])
+    (distillation_crn.py:467-477); fixtures student_tiny_feat0..4 = rows 2..5 (segments 1 and 2, both streams) from the genuine
+    reference module."""
+    from speech_enhancement_mi_amd.distillation_crn import TemporalCRN as Student
+    m = Student(**TINY)
+    sd = synth.make_state_dict(spec_of_variant(TINY, 2), seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.cuda()
+    mix, _ = synth.synth_utterances(2, 8000 + 4800, 3, seed=7)
+    y, feats = m.realtime_process(_cuda(mix[..., :8000]))
+    assert rel_rms(y.cpu().numpy(), vgolden["student_tiny_out"]) < TOL
+    assert len(feats) == 5 == len(m.get_channel_num())
+    for i, (f, ch) in enumerate(zip(feats, m.get_channel_num())):
+        ref = vgolden[f"student_tiny_feat{i}"]
+        assert f.shape[1] == ch and tuple(f.shape[1:]) == ref.shape[1:], (i, f.shape, ref.shape)
+        assert rel_rms(f[2:6].cpu().numpy(), ref) < 2e-5, i
+    # the per-segment path carries state like the fused one: continuation matches the reference too
+    y2, _ = m.realtime_process(_cuda(mix[..., 8000:]), True)
+    assert rel_rms(y2.cpu().numpy(), vgolden["student_tiny_cont_out"]) < TOL
+    # forward() returns the same five maps for one segment
+    m.return_features = False
+    y3, none = m.realtime_process(_cuda(mix[..., :8000]))
+    assert none is None and rel_rms(y3.cpu().numpy(), vgolden["student_tiny_out"]) < TOL
+
+
+# ---- config 3: FullSubNet at B = 256 ------------------------------------------------------------------------------------
+def test_fsn_batch256_properties():
+    """BASELINE configs[2] size (B*F = 51 456 sub-band rows): batch independence vs B = 4 (all norms / states are per stream),
+    bit-repeatability after reset, finite output - the size-independent properties test_full_size_batch256_properties uses."""
+    from speech_enhancement_mi_amd import engine
+    cfg = FSN_FULL
+    e = engine.FsnEngine(cfg["num_freqs"], cfg["num_mics"], cfg["fb_model_hidden_size"], cfg["sb_model_hidden_size"], cfg["num_layers"],
+                         cfg["sb_num_neighbors"], cfg["fb_num_neighbors"], cfg["look_ahead"], cfg["sample_rate"], cfg["segment_length"],
+                         cfg["win_length"], cfg["hop_length"], cfg["n_fft"])
+    e.load_state_dict(synth.make_state_dict(fsn_spec(cfg), seed=0))
+    L = 6400
+    base, _ = synth.synth_utterances(4, L, 3, seed=23)
+    big = np.ascontiguousarray(np.tile(base, (64, 1, 1)))
+    y_big = e.realtime_process(_cuda(big)).cpu().numpy()
+    assert y_big.shape == (256, L) and np.isfinite(y_big).all()
+    y_small = e.realtime_process(_cuda(base)).cpu().numpy()
+    for i in (0, 1, 2, 3, 101, 255):
+        assert rel_rms(y_big[i], y_small[i % 4]) < 5e-6, i
+    assert np.array_equal(e.realtime_process(_cuda(big)).cpu().numpy(), y_big)
+    # prefix consistency: segments fully inside a prefix do not depend on what follows
+    y_prefix = e.realtime_process(_cuda(base[..., :4800])).cpu().numpy()
+    assert rel_rms(y_prefix[:, :3200], y_small[:, :3200]) < 5e-6
+
+
+def test_fsn_train_true_raises():
+    from speech_enhancement_mi_amd.fullsubnet import FullSubNet
+    m = FullSubNet(**dict(FSN_FULL, fb_model_hidden_size=16, sb_model_hidden_size=16)).cuda()
+    with pytest.raises(NotImplementedError, match="train=True"):
+        m.realtime_process(torch.zeros(1, 3, 3200, device="cuda"), None, False, True)
+
+
+# ---- config 5: the 3-term split-bf16 mode against the REFERENCE goldens ---------------------------------------------------
+@pytest.mark.parametrize("tag,cfg,variant,L", [("student_full400", STUDENT400, 2, 6400), ("elu_full400", FULL400, 1, 6400),
+                                               ("full400", FULL400, 0, 8000), ("full512", FULL512, 0, 8000)])
+def test_bf16x3_mode_vs_reference_goldens(golden, vgolden, tag, cfg, variant, L):
+    """precision = 2 (hi*hi + hi*mid + mid*hi on the bf16 matrix cores, fp32 accumulation; recurrence, norms and storage
+    fp32) against the outputs of the genuine reference modules, at north_star's bar: relative RMS < 1e-4 and SI-SDR of
+    build and reference against the clean signal within 0.02 dB."""
+    e = _engine(cfg, variant, precision=2)
+    mix, clean = synth.synth_utterances(2, L + (3200 if tag == "full400" else 0), 3, seed=7)
+    y = e.realtime_process(_cuda(mix[..., :L])).cpu().numpy()
+    ref = (vgolden if variant else golden)[f"{tag}_out"]
+    err = rel_rms(y, ref)
+    assert err < TOL, err
+    d = synth.si_sdr(clean[:, :L], y) - synth.si_sdr(clean[:, :L], ref)
+    assert np.abs(d).max() < TOL_DB, d
+    if tag == "full400":
+        y2 = e.realtime_process(_cuda(mix[..., L:]), flag=True).cpu().numpy()
+        assert rel_rms(y2, golden["full400_cont_out"]) < TOL
+
+
+def test_student_batch1024_bf16x3():
+    """BASELINE configs[4] size: the distilled student at B = 1024 in the fast mode.  Stream i of the big batch equals the
+    same utterance in a batch of 4 run by the fp32-accurate engine to 1e-4 (parity of the mode is pinned against the
+    reference goldens above; this checks the B = 1024 launch geometry), deterministic, finite."""
+    e3, e6 = _engine(STUDENT400, 2, precision=2, seed=1), _engine(STUDENT400, 2, precision=0, seed=1)
+    L = 9600
+    base, clean = synth.synth_utterances(4, L, 3, seed=71)
+    big = np.ascontiguousarray(np.tile(base, (256, 1, 1)))
+    y_big = e3.realtime_process(_cuda(big)).cpu().numpy()
+    assert y_big.shape == (1024, L) and np.isfinite(y_big).all()
+    y_ref = e6.realtime_process(_cuda(base)).cpu().numpy()
+    for i in (0, 1, 2, 3, 513, 1023):
+        assert rel_rms(y_big[i], y_ref[i % 4]) < TOL, i
+        assert abs(synth.si_sdr(clean[i % 4], y_big[i]) - synth.si_sdr(clean[i % 4], y_ref[i % 4])) < TOL_DB
+    assert np.array_equal(e3.realtime_process(_cuda(big)).cpu().numpy(), y_big)
+
+
+def test_set_precision_on_dropin_class(golden):
+    from speech_enhancement_mi_amd import TemporalCRN
+    m = TemporalCRN(**FULL400)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of(FULL400), seed=0).items()})
+    m = m.cuda().set_precision("bf16x3")
+    mix, _ = synth.synth_utterances(2, 8000, 3, seed=7)
+    y = m.realtime_process(_cuda(mix))
+    assert m._eng_precision == 2
+    assert rel_rms(y.cpu().numpy(), golden["full400_out"]) < TOL
+    with pytest.raises(ValueError):
+        m.set_precision("int4")
+
+
+def test_config_struct_size_matches_library():
+    import ctypes
+    from speech_enhancement_mi_amd import engine
+    lib = engine.load_library()
+    assert lib.se_config_size() == ctypes.sizeof(engine.SeConfig) == 4 * (1 + 8 + 12)
+    assert lib.fsn_config_size() == ctypes.sizeof(engine.FsnConfig)
