@@ -158,6 +158,16 @@ int fsn_realtime_process(fsn_engine *e, const float *mixture, int batch, int64_t
 int fsn_read_tap(fsn_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
 double fsn_flops_per_frame(const fsn_engine *e);
 
+/* ---- training loss (reference CRN.py:593-617 compute_loss) ------------------------------------------------
+ * SI-SNR term, utility.cal_si_snr (utility.py:207-223), device-resident: separated / source [B, L] fp32 device tensors,
+ * lens [B] int64 device tensor (samples that count per utterance).  fwd writes the per-utterance SI-SNR in dB to per_utt [B]
+ * and 8 doubles of saved scalars per utterance to stats; bwd writes grad [B, L] = gscale[0] * d SI-SNR_b / d separated
+ * (gscale is a 1-element device tensor: upstream gradient / B for the batch mean).  Enqueued on `stream`, no sync. */
+int se_loss_sisnr_fwd(const float *separated, const float *source, const int64_t *lens, int batch, int64_t length, float *per_utt,
+                      double *stats, void *stream);
+int se_loss_sisnr_bwd(const float *separated, const float *source, const int64_t *lens, int batch, int64_t length, const double *stats,
+                      const float *gscale, float *grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,15 +154,8 @@ class TemporalCRN(nn.Module):
         return eng.realtime_process(mixture.contiguous().float(), flag=bool(flag))
 
     def compute_loss(self, source, pred_source, length):
-        """loss = 0.7 * stoi_loss + 0.3 * (-SI-SNR)  (CRN.py:609-617).  The SI-SNR term restates
-        utility.cal_si_snr (utility.py:207-223).  The STOI term depends on torchaudio 0.7.2 Resample/Spectrogram
-        (utility.py:821-916), absent here: parity unpinned, not restated in this round."""
-        from .losses import cal_si_snr, stoi_loss
-        stoi = stoi_loss(source, pred_source, length)
-        sisnr = -cal_si_snr(pred_source, source, length)
-        loss = 0.7 * stoi + 0.3 * sisnr
-        if torch.isnan(loss):
-            stoi = stoi.fill_(0.0)
-            sisnr = sisnr.fill_(0.0)
-            loss = loss.fill_(0.0)
-        return loss, stoi, sisnr
+        """loss = 0.7 * stoi_loss + 0.3 * (-SI-SNR), NaN -> zeros  (CRN.py:593-617); returns (loss, stoi, sisnr) on the
+        device of `pred_source` with gradients to it.  See losses.py: device-resident restatement of utility.stoi_loss
+        (torchaudio boundary unpinned) and a fused HIP SI-SNR kernel pair."""
+        from .losses import compute_loss
+        return compute_loss(source, pred_source, length)

@@ -21,7 +21,7 @@ EXPORTS = [
     "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
-    "fsn_read_tap", "fsn_flops_per_frame",
+    "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
 ]
 
 
@@ -88,6 +88,8 @@ def load_library():
     L.fsn_read_tap.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
     L.fsn_flops_per_frame.argtypes = [vp]
     L.fsn_flops_per_frame.restype = C.c_double
+    L.se_loss_sisnr_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp]
+    L.se_loss_sisnr_bwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, vp]
     L.se_profile.argtypes = [vp, C.c_int]
     L.se_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     _lib = L

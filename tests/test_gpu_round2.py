@@ -177,3 +177,60 @@ def test_config_struct_size_matches_library():
     lib = engine.load_library()
     assert lib.se_config_size() == ctypes.sizeof(engine.SeConfig) == 4 * (1 + 8 + 12)
     assert lib.fsn_config_size() == ctypes.sizeof(engine.FsnConfig)
+
+
+# ---- 8f-2: device-resident training loss ---------------------------------------------------------------------------------
+def _loss_fixture():
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from loss_inputs import make_loss_inputs
+    return np.load(os.path.join(ROOT, "tests", "golden", "loss_golden.npz")), make_loss_inputs()
+
+
+def test_compute_loss_on_gpu_vs_reference_fixture():
+    """TemporalCRN.compute_loss on GPU tensors: the 3-tuple and d loss / d pred against the genuine reference's values
+    (tests/golden/make_golden_loss.py).  Everything stays on the device: the fused HIP SI-SNR kernel pair (se_loss_sisnr_*)
+    and the batched STOI restatement; the result tensors live on the GPU."""
+    from speech_enhancement_mi_amd import TemporalCRN
+    lg, (clean, pred, lens) = _loss_fixture()
+    m = TemporalCRN(**TINY).cuda()
+    src = _cuda(clean)
+    p = _cuda(pred).requires_grad_(True)
+    loss, stoi, sisnr = m.compute_loss(src, p, torch.from_numpy(lens).cuda())
+    assert loss.is_cuda and stoi.is_cuda and sisnr.is_cuda
+    loss.backward()
+    got = np.array([float(loss.detach()), float(stoi.detach()), float(sisnr.detach())])
+    assert np.abs(got - lg["loss"]).max() < 1e-4, got
+    g = p.grad.cpu().numpy()
+    ref = lg["grad_pred_s5"]
+    assert np.linalg.norm(g[:, ::5] - ref) / np.linalg.norm(ref) < 2e-3
+    assert np.all(g[1, lens[1]:] == 0)
+
+
+def test_sisnr_hip_kernels_vs_torch_autograd():
+    """se_loss_sisnr_fwd / _bwd against the torch restatement of utility.cal_si_snr and its autograd gradient: ragged lengths,
+    a high-SNR pair (|s - s_t| << |s_t|) and a negatively correlated pair."""
+    from speech_enhancement_mi_amd import losses
+    rng = np.random.default_rng(5)
+    B, L = 6, 20011
+    r = rng.standard_normal((B, L)).astype(np.float32)
+    s = (r + 0.3 * rng.standard_normal((B, L))).astype(np.float32)
+    s[1] = r[1] + 1e-3 * rng.standard_normal(L).astype(np.float32)   # ~60 dB
+    s[2] = -0.5 * r[2] + 0.1 * rng.standard_normal(L).astype(np.float32)
+    s[3] += 0.7                                                         # a DC offset is removed
+    lens = np.array([L, L, 12345, 1, 777, 20000])
+    s_cpu = torch.from_numpy(s).requires_grad_(True)
+    v_ref = losses._cal_si_snr_torch(s_cpu, torch.from_numpy(r), torch.from_numpy(lens))
+    v_ref.backward()
+    s_gpu = _cuda(s).requires_grad_(True)
+    v = losses.cal_si_snr(s_gpu, _cuda(r), torch.from_numpy(lens))
+    v.backward()
+    assert abs(float(v.detach()) - float(v_ref.detach())) < 2e-4 * max(1.0, abs(float(v_ref.detach())))
+    g, g_ref = s_gpu.grad.cpu().numpy(), s_cpu.grad.numpy()
+    for i in range(B):
+        if lens[i] < 2:
+            continue
+        assert np.linalg.norm(g[i] - g_ref[i]) <= 2e-3 * np.linalg.norm(g_ref[i]) + 1e-12, i
+        assert np.all(g[i, lens[i]:] == 0)
