@@ -142,11 +142,34 @@ def launcher_selftest(args):
 # ---------------------------------------------------------------------------------------------------------------
 # baselines and roofline helpers
 # ---------------------------------------------------------------------------------------------------------------
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a 1-GPU job a
+    16-CPU share of a 256-thread host; 256 OpenMP threads on that share spin against each other and never finish)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def progress(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(cfg, sd, variant=0, seconds_budget=20.0):
     """Oracle (C restatement of the reference path, OpenMP) on the host cores, bounded sample."""
     from oracle import crn_oracle as orc
     from speech_enhancement_mi_amd import synth
-    avail = len(os.sched_getaffinity(0))
+    avail = host_cpu_share()
     # one stream per thread (the oracle parallelises over streams and channels); more threads than streams only add
     # OpenMP overhead, so the baseline uses min(available cores, 32) threads and says so in `cores`
     cores = orc.lib().crn_oracle_set_threads(max(1, min(avail, 32)))
@@ -174,7 +197,7 @@ def cpu_baseline_torch(cfg, sd, seconds_budget=30.0):
     import torch
     from speech_enhancement_mi_amd import synth
     from speech_enhancement_mi_amd.training import TrainableCRN
-    avail = len(os.sched_getaffinity(0))
+    avail = host_cpu_share()
     prev = torch.get_num_threads()
     torch.set_num_threads(avail)
     model = TrainableCRN(**cfg)
@@ -194,6 +217,7 @@ def cpu_baseline_torch(cfg, sd, seconds_budget=30.0):
         for B in (1, 32):
             mix, _ = synth.synth_utterances(B, 48000, 3, seed=7)
             x = torch.from_numpy(mix)
+            progress(f"cpu_baseline_torch: B={B}, {avail} threads")
             model.realtime_process_train(x[:1])  # warm-up utterance
             best = None
             for _ in range(3):
@@ -208,6 +232,21 @@ def cpu_baseline_torch(cfg, sd, seconds_budget=30.0):
                             cpu=cpu_model, sample=f"best of <=3 realtime_process of {B} x 3 s utterances ({nseg} frames each), torch {torch.__version__} CPU, {avail} threads"))
     torch.set_num_threads(prev)
     return out
+
+
+def cpu_baseline_torch_guarded(args, timeout=240):
+    """cpu_baseline_torch in a CHILD process (CPU only, never touches the GPU) under a hard timeout, so that a slow host
+    cannot stall the bench line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--nfft", str(args.nfft), "--model", args.model]
+    try:
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("[")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return dict(error=f"worker exited {r.returncode}", stderr=r.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(error=f"PyTorch-CPU baseline did not finish within {timeout} s on {host_cpu_share()} CPUs")
 
 
 def kernel_source_sha():
@@ -363,8 +402,10 @@ def bench_crn(args, rank, local_rank, world, backend):
     out = torch.empty((B, L), dtype=torch.float32, device="cuda")
     nseg = seg_count(L)
 
+    progress(f"timed region: {args.warmup} + {args.steps} steps")
     dt = timed_region(lambda: eng.realtime_process(mix, out=out), args.steps, args.warmup, world, backend)
     assert bool(torch.isfinite(out).all()), "non-finite output"
+    progress(f"{world * B * nseg * args.steps / dt:.0f} frames/s; profiled step")
     frames = world * B * nseg * args.steps
     value = frames / dt
 
@@ -417,9 +458,10 @@ def bench_crn(args, rank, local_rank, world, backend):
     if rank == 0:
         result["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
+            progress("cpu_baseline: C oracle")
             result["cpu_baseline"] = cpu_baseline(cfg, sd, variant)
             if variant == 0:
-                result["cpu_baseline_torch"] = cpu_baseline_torch(cfg, sd)
+                result["cpu_baseline_torch"] = cpu_baseline_torch_guarded(args)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
@@ -442,6 +484,7 @@ def parse_args(argv=None):
     ap.add_argument("--train-loss", choices=["full", "sisnr"], default="sisnr",
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dtype", choices=sorted(PRECISIONS), default="f32",
                     help="f32 = fp32-accurate contractions (headline); bf16x3 = 3-term split-bf16 (inside the 1e-4 parity bar; BASELINE config 5: "
                          "--model student --dtype bf16x3 --batch 1024); f16 = fp16 MFMA operands (outside the parity bar)")
@@ -450,6 +493,12 @@ def parse_args(argv=None):
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_worker:  # child of cpu_baseline_torch_guarded: CPU only
+        from speech_enhancement_mi_amd import synth
+        cfg = crn_cfg(args.nfft, args.model)
+        spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=0)
+        print(json.dumps(cpu_baseline_torch(cfg, synth.make_state_dict(spec, seed=0))))
+        return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:

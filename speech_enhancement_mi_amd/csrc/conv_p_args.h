@@ -1,0 +1,96 @@
+// conv_p_args.h - argument structs of the plane-layout convolution path (kernels: conv_p.hip.h), shared with the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_args.h"
+
+namespace se {
+
+constexpr int kPNiMax = 20;   // LDS-DMA instructions per thread per chunk: PL * CO * Npos <= 256 * kPNiMax (host-checked)
+constexpr unsigned kPOob = 0xFFFFFFF0u;  // buffer offset beyond every ring: the bounds check returns zeros
+
+enum ConvPOut : int { kPOutR = 0, kPOutP = 1, kPOutBlend = 2, kPOutStats = 3 };
+
+struct ConvPArgs {
+    // ---- input: P layout, one allocation holding every ring slot ----
+    const uint4 *xbase;     // ring base
+    unsigned xbytes;        // bytes of the ring (buffer descriptor range)
+    long cur_off, prev_off; // uint4 offsets of the current / history slot inside the ring (prev_off < 0: no history)
+    int C8;                 // channel octets of the input tensor
+    // ---- geometry (as ConvArgs) ----
+    int Ci, Co, CoPad, T, Fi, FP;
+    int s, colpad, tlo_off, ngroup, dil, grouped, ntap;
+    int rowgrp[kMaxTaps], coloff[kMaxTaps];
+    int nchunk, tiles_per_wg, St;
+    const uint4 *wx;        // [nchunk][npair][PL][MT][64] weight fragments
+    const float *bias;      // [CoPad] in GEMM-row order
+    int act;                // activation on rows [relu_lo, relu_hi): 1 ReLU, 2 ELU
+    int relu_lo, relu_hi;
+    // ---- output ----
+    int out_mode;           // ConvPOut
+    float *y;               // kPOutR: R layout [b][Co8][npos][8]
+    long y_stream;          // floats per stream
+    int y_npos;             // positions per octet (T * oT)
+    int oT, oo;             // output position = t * oT + oo + m
+    int row_perm;           // 1: GEMM rows are permuted so that a lane holds 8 consecutive channels (P-layout outputs)
+    uint4 *yp;              // kPOutP / kPOutBlend: P layout [b][Co8][PL][T][Fy]
+    long yp_stream;         // uint4 per stream
+    int Fy;                 // row length of the P output; position (t, m) -> column oo + m
+    int Cy;                 // channels of the output tensor
+    // statistics of the stored values (rows [stats_lo, stats_hi)) -> stats[(b*nslot + slot0 + blockIdx.x)*2 + {0,1}]
+    float *stats;
+    int stats_nslot, stats_slot0, stats_lo, stats_hi;
+    int valid_m;            // positions with m >= valid_m are not stored / counted (odd parity of a transposed conv: Fi - 1)
+    int par_rows;           // 1: GEMM rows (2c, 2c+1) = even / odd output-frequency parity of channel c of a transposed convolution
+                            // merged into one launch (zero weights where a parity does not use a tap); the odd row of the last
+                            // position (m == FP - 1) does not exist and is left out of the statistics
+    // ---- fused decoder skip gate (kPOutBlend): rows (2c, 2c+1) = (residualmask_c, residual_c) ----
+    const float *bl_ydec;   // R layout of the transposed convolution of this block: [b][Cy8][T * bl_oT][8]
+    long bl_stream;
+    int bl_oT, bl_Fh, bl_Fo; // decoder output column f lives at t * bl_oT + (f & 1) * bl_Fh + (f >> 1); f >= bl_Fo -> zero pad
+    const float *bl_nw, *bl_nb, *bl_mnw, *bl_mnb;
+    SlabStats bl_sy, bl_su;
+};
+
+struct FeatPArgs {
+    const cf2 *spec;
+    long sB, sM, sT, sF;
+    uint4 *out;      // P[b][0][pl][t][f]
+    long out_stream; // uint4 per stream
+    int M, T, F, atan2_phase;
+};
+
+struct GlnPArgs {
+    const float *x;     // R layout [b][C8][npos_in][8]
+    long x_stream;      // floats per stream
+    int C, C8, T, F;    // output geometry: positions (t, f), t < T, f < F
+    int in_oT;          // input position of (t, f) = t * in_oT + f
+    const float *w, *b; // [C]
+    SlabStats st;
+    uint4 *y;           // mode 0: P[b][o][pl][t][f]   mode 1: A planes of the GRU input GEMM, [pl][b*T + t][o][f] (K = C8*F*8)
+    long y_stream;      // mode 0: uint4 per stream
+    long y_plane;       // mode 1: uint4 per plane (= B*T*C8*F)
+    int mode;
+};
+
+struct Gln2PArgs {
+    const float *x;
+    const float *w, *b;  // [D]
+    uint4 *y;            // P[b][o][pl][t][f]
+    long y_stream;
+    int T, F, C, C8, eps_mode;
+};
+
+struct MaskPArgs {
+    const float *y;   // R layout [b][1][T * Fh][8]
+    long y_stream;
+    int Fh;
+    const float *nw, *nb;
+    SlabStats st;
+    const cf2 *spec;
+    long sB, sT, sF;
+    cf2 *out;
+    long oB, oT, oF;
+    int T, F;
+};
+
+}  // namespace se

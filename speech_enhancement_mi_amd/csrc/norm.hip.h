@@ -218,6 +218,31 @@ __global__ __launch_bounds__(256) void k_gln_ew(GlnEwArgs a) {
 
 #endif  // norm kernels
 
+// R layout (conv_p.hip.h: [b][octet][t*F + f][8] fp32) -> normalised [T][C*F] fp32 rows, the A operand of the bottleneck's input
+// GEMM (CRN.py:476-478: reshape [B, C, F, T] -> [B, C*F, T] -> permute); one thread per (octet, position)
+#if !defined(SE_AUX_KERNELS) && !defined(SE_NO_NORM_KERNELS)
+__global__ __launch_bounds__(256) void k_gln_r2t(GlnEwArgs a, long x_stream) {
+    __shared__ float sm[2];
+    const int b = blockIdx.y;
+    float mean, inv;
+    slab_mean_inv(a.st, b, sm, mean, inv);
+    const int TF = a.T * a.F, C8 = (a.C + 7) / 8;
+    const float *x = a.x + (long)b * x_stream;
+    float *y = a.y + (long)b * a.st.n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < C8 * TF; i += gridDim.x * 256) {
+        const int o = i / TF, pos = i - o * TF, t = pos / a.F, f = pos - t * a.F;
+        const float4 *src = reinterpret_cast<const float4 *>(x + ((long)o * TF + pos) * 8);
+        const float4 u0 = src[0], u1 = src[1];
+        const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ch = o * 8 + c;
+            if (ch < a.C) y[((long)t * a.C + ch) * a.F + f] = (v[c] - mean) * inv * a.w[ch] + a.b[ch];
+        }
+    }
+}
+#endif  // norm kernels
+
 struct BlendEwArgs {
     const float *y, *uv;
     float *out;

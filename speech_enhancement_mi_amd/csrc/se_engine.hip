@@ -24,6 +24,7 @@
 
 #include "../../include/se_engine.h"
 #include "conv_dispatch.h"
+#include "convp_dispatch.h"
 #include "fsn.hip.h"
 #include "fft_lds.h"
 #include "gemm.hip.h"
@@ -132,6 +133,10 @@ struct se_engine {
     DevBuf enc_g[SE_MAX_LEVELS];           // CRN_ELU: gated encoder output before the norm
     DevBuf pin[3][2], pre_g, pre_stats[3];  // CRN_ELU preconv chain (inputs ping-ponged: they carry 4 history columns)
     DevBuf yseg;
+    // second-generation convolution path (conv_p.hip.h): activations as split-bf16 planes; SE_PATH=0 selects the first generation
+    struct se_convp_state *cp = nullptr;
+    int path = 1;
+    bool use_p = false;
 
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
@@ -782,6 +787,8 @@ int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, lon
     return 0;
 }
 
+uint4 *decin_p(se_engine *e, int slot);  // convp_engine.inc.h: decoder-input ring slot of the plane path
+
 // Stage 2: the recurrent bottleneck (CRN.py:476-481, 256-282)  gru_in[cur] -> dec_in[cur]
 // `overlapped`: the stage shares the chip with the encoder / decoder streams.  The GRU step then uses the small-footprint
 // kernel (k_gru_step: 54 VGPRs, 6 KB LDS, W_hh straight from L2) whose waves fit next to two resident convolution
@@ -830,6 +837,14 @@ int stage_bottleneck(se_engine *e, int cur, hipStream_t st, bool overlapped = fa
         in_dim = H;
     }
     if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
+    if (e->use_p) {  // decoder input in the plane layout
+        const int PL = operand_planes(e->precision), C = e->Ch[L], C8 = (C + 7) / 8;
+        ProfScope ps(e, "k_gln2_p", "gln", 0, st);
+        Gln2PArgs g{e->fc_out.p, e->gnw.p, e->gnb.p, decin_p(e, cur), (long)C8 * PL * T * e->F[L], T, e->F[L], C, C8, e->eps_mode};
+        launch_k_gln2_p(PL, dim3(B), st, g);
+        HIPCHECK(e, hipGetLastError());
+        return 0;
+    }
     return launch_gln(e, e->fc_out.p, e->dec_in[cur].p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st);
 }
 
@@ -881,14 +896,27 @@ int stage_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long
     return 0;
 }
 
+}  // namespace
+
+#include "convp_engine.inc.h"
+
+namespace {
+
+int run_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
+    return e->use_p ? stage_encoder_p(e, cur, prev, spec, sB, sM, sT, sF, st) : stage_encoder(e, cur, prev, spec, sB, sM, sT, sF, st);
+}
+int run_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long sF, cf2 *out, long oB, long oT, long oF, hipStream_t st) {
+    return e->use_p ? stage_decoder_p(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st) : stage_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
+}
+
 int forward_dev(se_engine *e, const cf2 *spec, long sB, long sM, long sT, long sF, cf2 *out, long oB, long oT, long oF,
                 hipStream_t st) {
     const int prev = e->slot, cur = (e->slot + 1) % kRing;
     e->slot = cur;
     int rc;
-    if ((rc = stage_encoder(e, cur, prev, spec, sB, sM, sT, sF, st))) return rc;
+    if ((rc = run_encoder(e, cur, prev, spec, sB, sM, sT, sF, st))) return rc;
     if ((rc = stage_bottleneck(e, cur, st))) return rc;
-    return stage_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
+    return run_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
 }
 
 // nseg > 1: one launch for nseg consecutive segments (segment y reads off + y*seg_off, writes spec + y*seg_spec)
@@ -924,6 +952,11 @@ int ensure_ready(se_engine *e) {
     const bool replanned = !e->weights_ready;
     int rc = prepare_weights(e);
     if (rc) return rc;
+    if (replanned) {
+        e->use_p = e->path != 0 && convp_supported(e);
+        if (e->use_p && (rc = prepare_weights_p(e))) return rc;
+        if (e->use_p && e->B > 0) select_all_p(e);
+    }
     if (replanned && e->B > 0)  // new weights re-made the plans with their default tiling: restore the per-batch choice
         for (int i = 0; i < SE_MAX_LEVELS; i++)
             for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].skipm, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
@@ -989,6 +1022,8 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_CONV_SMALL16")) e->conv_small16 = atoi(s);
     if (const char *s = getenv("SE_SKIP_FUSE")) e->skip_fuse = atoi(s);
     if (const char *s = getenv("SE_DEC_MERGE")) e->dec_merge = atoi(s);
+    if (const char *s = getenv("SE_PATH")) e->path = atoi(s);
+    e->cp = new se_convp_state();
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) e->num_cu = ncu;
@@ -1013,6 +1048,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     // opt in to large dynamic LDS for the FFT kernels
     aux_set_fft_lds((int)stft_lds_bytes(K, N), (int)istft_lds_bytes(T, N));
     conv_set_attributes();
+    conv_p_set_attributes();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
@@ -1053,6 +1089,7 @@ void se_destroy(se_engine *e) {
         dev_free(l.pre_nw); dev_free(l.pre_nb);
         if (i < 3) { dev_free(e->pin[i][0]); dev_free(e->pin[i][1]); dev_free(e->pre_stats[i]); }
     }
+    free_state_p(e);
     delete e;
 }
 
@@ -1140,6 +1177,10 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
             if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
             HIPCHECK(e, hipMemsetAsync(e->hbuf[l][p].p, 0, (size_t)B * H * sizeof(float), st));
         }
+    if (e->use_p) {
+        select_all_p(e);
+        if ((rc = alloc_state_p(e, st))) return rc;
+    }
     if ((rc = dev_alloc(e, e->gru_sync, 128))) return rc;
     HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 128 * sizeof(float), st));
     for (int l = 0; l < 4; l++) e->hcur[l] = 0;
@@ -1164,6 +1205,11 @@ int se_reset_stream(se_engine *e, int stream_index, void *stream) {
     const int T = e->T, H = e->H, b = stream_index;
     // conv time buffers = the tail of the current ring slot (the next window reads it as history)
     for (int i = 0; i < e->L; i++) {
+        if (e->use_p) {  // plane path: [slot][b][C8][PL][T][F] pieces of 16 bytes
+            const size_t per16 = (size_t)(e->cp->slot_elems[i] / e->B);
+            HIPCHECK(e, hipMemsetAsync(e->cp->xinP[i].p + ((size_t)e->slot * e->cp->slot_elems[i] + per16 * b) * 4, 0, per16 * 16, st));
+            continue;
+        }
         const size_t per = (size_t)e->Ch[i] * T * e->F[i];
         HIPCHECK(e, hipMemsetAsync(e->xin[i][e->slot].p + per * b, 0, per * sizeof(float), st));
     }
@@ -1445,13 +1491,13 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                                           reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, sE, (int)ns, P, (long)(spec_n / 2)))) return rc;
                 }
                 if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
-                if ((rc = stage_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
+                if ((rc = run_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
                 HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
                 HIPCHECK(e, hipStreamWaitEvent(sG, e->ev_enc[cur], 0));
                 if ((rc = stage_bottleneck(e, cur, sG, /*overlapped=*/true))) return rc;
                 HIPCHECK(e, hipEventRecord(e->ev_gru[cur], sG));
                 HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[cur], 0));
-                if ((rc = stage_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
+                if ((rc = run_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
                 if (i % kFftSub == kFftSub - 1 || i == cn - 1) {
                     const long i0 = i - i % kFftSub;
                     if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i0), T * F, F, 1, e->B,
@@ -1487,6 +1533,21 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
     const float *src = nullptr;
     int C = 0, F = 0, idx = -1;
     bool gru_layout = false;
+    if (e->use_p && strncmp(name, "ft", 2)) {  // plane path: operand tensors are split-bf16 planes, summed back on the host
+        se_convp_state &S = *e->cp;
+        const float *psrc = nullptr;
+        if (!strcmp(name, "feat")) { psrc = S.xinP[0].p + (size_t)cur * S.slot_elems[0] * 4; C = e->Ch[0]; F = e->F[0]; }
+        else if (!strcmp(name, "gru")) { psrc = S.decinP[cur].p; C = e->Ch[L]; F = e->F[L]; }
+        else if (sscanf(name, "enc%d", &idx) == 1 && idx >= 0 && idx < L - 1) { psrc = S.xinP[idx + 1].p + (size_t)cur * S.slot_elems[idx + 1] * 4; C = e->Ch[idx + 1]; F = e->F[idx + 1]; }
+        else if (sscanf(name, "dec%d", &idx) == 1 && idx >= 0 && idx < L - 1) { psrc = S.decP[idx].p; C = e->Ch[L - 1 - idx]; F = e->F[L - 1 - idx]; }
+        if (psrc) {
+            const size_t n = (size_t)B * C * T * F;
+            if (count) *count = (int64_t)n;
+            if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+            return p_to_host(e, psrc, C, F, host_out, st, true);
+        }
+        idx = -1;  // enc{L-1} (the fp32 GRU input) and unknown names fall through
+    }
     if (!strcmp(name, "feat")) { src = e->xin[0][cur].p; C = e->Ch[0]; F = e->F[0]; }
     else if (!strcmp(name, "gru")) { src = e->dec_in[cur].p; C = e->Ch[L]; F = e->F[L]; }
     else if (sscanf(name, "enc%d", &idx) == 1 && idx >= 0 && idx < L) {
@@ -1585,6 +1646,10 @@ int se_export_state(se_engine *e, const char *name, float *host_out, int64_t cap
         if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
         std::vector<float> h(nsrc);
         HIPCHECK(e, hipStreamSynchronize(st));
+        if (e->use_p && !is_pbuf) {
+            int rc = p_to_host(e, e->cp->xinP[idx].p + (size_t)e->slot * e->cp->slot_elems[idx] * 4, C, F, h.data(), st, false);
+            if (rc) return rc;
+        } else
         HIPCHECK(e, hipMemcpy(h.data(), (is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
@@ -1616,6 +1681,7 @@ int se_import_state(se_engine *e, const char *name, const float *host_in, int64_
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) h[(bc * T + (T - P + p)) * F + f] = host_in[(bc * F + f) * P + p];
+        if (e->use_p && !is_pbuf) return host_to_p(e, h, C, F, e->cp->xinP[idx].p + (size_t)e->slot * e->cp->slot_elems[idx] * 4);
         HIPCHECK(e, hipMemcpy((is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
         return SE_OK;
     }
