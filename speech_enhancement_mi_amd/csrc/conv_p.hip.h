@@ -71,8 +71,11 @@ __device__ __forceinline__ void convp_stats_store(float *stats, int nslot, int s
 }
 
 template <int NTAP, int NT, int CO, int PL>
-__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
-    extern __shared__ __align__(16) uint4 planes[];  // [PL][CO][Npos]
+__global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
+    // LDS patch [PL][CO][Npos] of 16-byte pieces (plane-major: consecutive LDS-DMA lanes copy consecutive 16-byte pieces of one
+    // plane row, i.e. whole cache lines; an interleaved [pos][plane] image made every wave instruction touch three scattered
+    // runs and staged at 9 GB/s per CU)
+    extern __shared__ __align__(16) uint4 planes[];
     constexpr int NPAIR = (NTAP * CO + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;  // provably wave-uniform (LDS-DMA destination, tile ownership)
@@ -102,14 +105,14 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
     for (int i = 0; i < NT; i++) {
         const int pc = min(p0 + (cg + i * NCG) * 32 + l31, p1 - 1);
         const int t = (int)(((float)pc + 0.5f) * invFP), m = pc - t * a.FP;
-        lane_base[i] = (t - ta) * St + a.s * m;
+        lane_base[i] = ((t - ta) * St + a.s * m) * 16;  // byte offset inside plane 0
     }
     int toffL[NPAIR];  // per lane half: LDS offset of entry 2*step + half = (tap, octet), tap-major
 #pragma unroll
     for (int pr = 0; pr < NPAIR; pr++) {
         const int en = min(2 * pr + half, NTAP * CO - 1);  // a padded (zero-weight) entry reads any valid position
         const int tp = en / CO, oc = en - tp * CO;
-        toffL[pr] = oc * Npos + a.rowgrp[tp] * (a.grouped ? RT : a.dil) * St + a.coloff[tp];
+        toffL[pr] = (oc * Npos + a.rowgrp[tp] * (a.grouped ? RT : a.dil) * St + a.coloff[tp]) * 16;
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
             if (k < NI) {
                 const int it = tid + 256 * k;
                 if (it < items) {
-                    const int q = (int)(((float)it + 0.5f) * invNpos);  // plane * CO + oc
+                    const int q = (int)(((float)it + 0.5f) * invNpos);  // LDS slot = (pl * CO + oc) * Npos + pe
                     const int pe = it - q * Npos;
                     const int pl = q / CO, oc = q - pl * CO;
                     const int r = (int)(((float)pe + 0.5f) * invSt), col = pe - r * St;
@@ -165,6 +168,17 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
     const uint4 *wxw = a.wx + (long)mt * 64 + l31 * 2 + half;  // + (((ch*NPAIR + pr)*PL + plane)*MT) * 64
     const long wx_plane = (long)MT * 64, wx_pair = PL * wx_plane, wx_chunk = NPAIR * wx_pair;
 
+    const char *ldsb = reinterpret_cast<const char *>(planes);
+    const int plane_bytes = CO * Npos * 16;
+    // One B fragment = the PL planes of 8 channels at one patch position.  The address is made opaque right before its reads:
+    // otherwise the compiler hoists all NPAIR x NT x PL fragment addresses out of the chunk loop (hundreds of registers parked
+    // in AGPRs and read back one by one) - one v_add per fragment is free next to six MFMAs.
+    auto read_b = [&](int i, int pr, uint4 (&bf)[PL]) {
+        int off = lane_base[i] + toffL[pr];
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int p = 0; p < PL; p++) bf[p] = *reinterpret_cast<const uint4 *>(ldsb + off + p * plane_bytes);
+    };
     for (int ch = 0; ch < a.nchunk; ch++) {
         const uint4 *wc = wxw + ch * wx_chunk;
         uint4 fa_n[PL];
@@ -173,6 +187,8 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
         __syncthreads();  // previous chunk fully consumed
         stage(ch);
         __syncthreads();  // (the compiler drains vmcnt before the barrier: every wave's DMA pieces have landed)
+        uint4 bcur[PL], bnxt[PL];
+        read_b(0, 0, bcur);
 #pragma unroll
         for (int pr = 0; pr < NPAIR; pr++) {
             uint4 fa[PL];
@@ -184,15 +200,18 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < NT; i++) {
-                const int pos = lane_base[i] + toffL[pr];
+                // software pipeline, one fragment deep: the LDS reads of the NEXT (tile, K step) are issued before this
+                // fragment's MFMAs, whose 100-200 matrix-pipe cycles cover the LDS latency (one wave per SIMD: nothing else would)
+                if (i + 1 < NT) read_b(i + 1, pr, bnxt);
+                else if (pr + 1 < NPAIR) read_b(0, pr + 1, bnxt);
+                __builtin_amdgcn_sched_barrier(0);
                 f32x16 c = acc[i];
                 if (PL >= 2) {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[0]), a1 = __builtin_bit_cast(bf16x8, fa[PL > 1 ? 1 : 0]),
                                  a2 = __builtin_bit_cast(bf16x8, fa[PL > 2 ? 2 : 0]);
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, planes[pos]);
-                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, planes[CO * Npos + pos]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bcur[0]), b1 = __builtin_bit_cast(bf16x8, bcur[PL > 1 ? 1 : 0]);
                     if (PL == 3) {
-                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, planes[2 * CO * Npos + pos]);
+                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bcur[PL > 2 ? 2 : 0]);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);  // mid*mid
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);  // hi*lo
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);  // lo*hi
@@ -202,9 +221,12 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void k_conv_p(ConvPArgs a) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);  // hi*hi
                 } else {
                     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[0]), __builtin_bit_cast(h8, planes[pos]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[0]), __builtin_bit_cast(h8, bcur[0]), c, 0, 0, 0);
                 }
                 acc[i] = c;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < PL; p++) bcur[p] = bnxt[p];
             }
         }
     }

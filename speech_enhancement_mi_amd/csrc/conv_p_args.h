@@ -93,4 +93,23 @@ struct MaskPArgs {
     int T, F;
 };
 
+struct SkipPArgs {
+    const uint4 *x;       // res: P layout [b][C8][PL][T*F] of this ring slot
+    long x_stream;        // uint4 per stream
+    int C, C8, TF;        // channels (Cin = Cout = C), octets, positions per stream (T * Fr)
+    int T, Fr;
+    const uint4 *wx;      // [MT2][KP][PL][64] fragments: M tiles [0, MTh) = residualmask rows, [MTh, 2 MTh) = residual rows,
+                          // rows permuted so that register r of lane half h is channel mt*32 + 16 h + r
+    const float *cst;     // [6][Cp] per channel (Cp = MTh*32): residualmask bias, residual bias, norm w, norm b, residualnorm w, b
+    int MTh, KP;
+    int act;
+    const float *ydec;    // R layout of this block's transposed convolution [b][C8][T * 2 Fh][8], parity-planar
+    long y_stream;
+    int Fh, Fo;           // decoder column f at t * 2 Fh + (f & 1) * Fh + (f >> 1); f >= Fo: zero pad (CRN.py:389-392)
+    SlabStats sy;         // statistics of ydec from its producers
+    int eps_mode;
+    uint4 *out;           // P layout [b][C8][PL][T*Fr]
+    long out_stream;
+};
+
 }  // namespace se

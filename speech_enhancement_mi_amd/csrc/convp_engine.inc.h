@@ -23,10 +23,21 @@ struct ConvPPlan {
     struct Geo { int NT = 0, tpw = 0, n_wg = 0, grouped = 0; size_t lds = 0; long items = 0; } geo[16];
     int ngeo = 0;
     int npair = 0, terms = 6;
+    std::string name;  // launch-site label ("enc3", "skip0", ...): SE_CONVP_NT_<name>=n forces a tiling for experiments
+};
+
+struct SkipPPlan {  // k_skip_p: the whole skip gate of one decoder level, one workgroup per stream
+    SkipPArgs a{};
+    DevBuf wx, cst;
+    int KP = 0;
+    size_t lds = 0;
+    bool active = false;
+    double flops = 0;
 };
 
 struct PLevel {
     ConvPPlan enc, dec_even, dec_odd, skip, skipm;
+    SkipPPlan sk;
     bool dec_merged = false;
 };
 
@@ -139,10 +150,11 @@ void select_convp_geometry(se_engine *e, ConvPPlan &pl) {
     if (!pl.active) return;
     double best = 0;
     int pick = -1;
-    const int force = getenv("SE_CONVP_NT") ? atoi(getenv("SE_CONVP_NT")) : 0;
+    int force = getenv("SE_CONVP_NT") ? atoi(getenv("SE_CONVP_NT")) : 0;
+    if (const char *s = getenv(("SE_CONVP_NT_" + pl.name).c_str())) force = atoi(s);
     for (int k = 0; k < pl.ngeo; k++) {
         const ConvPPlan::Geo &g = pl.geo[k];
-        const int wgpc = (g.NT <= 4 && g.lds <= 80 * 1024) ? 2 : 1;  // k_conv_p<.., NT <= 4> is built for two workgroups per CU
+        const int wgpc = (g.NT <= 6 && g.lds <= 80 * 1024) ? 2 : 1;  // k_conv_p<.., NT <= 6> is built for two workgroups per CU
         const double rounds = std::ceil((double)g.n_wg * e->B / ((double)e->num_cu * wgpc));
         const double mfma = (double)pl.a.nchunk * pl.npair * g.NT * pl.terms * 32.0;
         const double stage = (double)pl.a.nchunk * g.items * 1.0 + pl.a.nchunk * 2500.0;  // ~16 B/cycle/CU + DMA latency and barriers per chunk
@@ -150,6 +162,13 @@ void select_convp_geometry(se_engine *e, ConvPPlan &pl) {
         const double cost = rounds * (wgpc * mfma + stage + epi);
         if (pick < 0 || cost < best) { best = cost; pick = k; }
         if (force && g.NT == force) { pick = k; break; }
+    }
+    if (getenv("SE_CONVP_VERBOSE")) {
+        const ConvPPlan::Geo &g = pl.geo[pick];
+        fprintf(stderr, "[conv_p] %-10s taps %2d Ci %3d rows %3d FP %3d: NT %2d tiles/wg %2d wgs/stream %2d lds %6zu items %5ld chunks %d pairs %d | candidates:", pl.name.c_str(),
+                pl.a.ntap, pl.a.Ci, pl.a.Co, pl.a.FP, g.NT, g.tpw, g.n_wg, g.lds, g.items, pl.a.nchunk, pl.npair);
+        for (int k = 0; k < pl.ngeo; k++) fprintf(stderr, " %d", pl.geo[k].NT);
+        fprintf(stderr, "\n");
     }
     const ConvPPlan::Geo &g = pl.geo[pick];
     pl.NT = g.NT; pl.grid_x = g.n_wg; pl.lds = g.lds;
@@ -178,6 +197,7 @@ void free_state_p(se_engine *e) {
     se_convp_state &S = *e->cp;
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
         for (ConvPPlan *p : {&S.pv[i].enc, &S.pv[i].dec_even, &S.pv[i].dec_odd, &S.pv[i].skip, &S.pv[i].skipm}) { dev_free(p->wx); dev_free(p->bias); }
+        dev_free(S.pv[i].sk.wx); dev_free(S.pv[i].sk.cst);
         dev_free(S.xinP[i]); dev_free(S.encR[i]); dev_free(S.decR[i]); dev_free(S.decP[i]);
     }
     for (int r = 0; r < kRing; r++) dev_free(S.decinP[r]);
@@ -208,6 +228,7 @@ int prepare_weights_p(se_engine *e) {
         int rc = plan_conv_p(e, S.pv[i].enc, Ci, Co, Fo, Fi, 2, 2, -2 * d, 3, d, Fi + 4, taps,
                              [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; }, *b, 0, Co, e->act, kPOutR);
         if (rc) return rc;
+        S.pv[i].enc.name = "enc" + std::to_string(i);
         ConvPArgs &a = S.pv[i].enc.a;
         a.oT = Fo; a.oo = 0; a.y_npos = T * Fo; a.y_stream = (long)((Co + 7) / 8) * T * Fo * 8;
         a.stats_lo = 0; a.stats_hi = Co;
@@ -224,6 +245,8 @@ int prepare_weights_p(se_engine *e) {
         auto wsel = [=](int ci, int co, int kf, int kt) { return wp[(((size_t)ci * Co + co) * 5 + kf) * 3 + kt]; };
         PLevel &pv = S.pv[j];
         int rc;
+        pv.dec_even.name = "dec" + std::to_string(j) + "_even"; pv.dec_odd.name = "dec" + std::to_string(j) + "_odd";
+        pv.skip.name = "skip" + std::to_string(j); pv.skipm.name = "skipstat" + std::to_string(j);
         pv.dec_merged = lvl == 0;  // the last block (2 mask channels): both parities as 4 GEMM rows of ONE launch
         if (pv.dec_merged) {
             std::vector<std::array<int, 4>> tu;
@@ -276,6 +299,53 @@ int prepare_weights_p(se_engine *e) {
             pv.skip.a.Cy = Co; pv.skip.a.Fy = Fr; pv.skip.a.oo = 0;
             pv.skip.flops = 2.0 * 2 * Co * Co * Fr * T;
             pv.skipm.flops = 0;  // recomputation, not algorithmic work
+            {   // streaming form (k_skip_p): M tiles [0, MTh) = residualmask, [MTh, 2 MTh) = residual; rows permuted like kPOutP
+                auto *mnw = param(e, p + "residualnorm.weight", Co);
+                auto *mnb = param(e, p + "residualnorm.bias", Co);
+                auto *nw = param(e, p + "norm.weight", Co);
+                auto *nb = param(e, p + "norm.bias", Co);
+                if (!mnw || !mnb || !nw || !nb) return SE_ERR_PARAM_MISSING;
+                SkipPPlan &sk = pv.sk;
+                const int PL = operand_planes(e->precision), C8 = (Co + 7) / 8, MTh = (Co + 31) / 32, KP = (C8 + 1) / 2, Cp = MTh * 32;
+                sk.active = e->skip_stream != 0 && MTh <= 2 && (KP == 1 || KP == 2 || KP == 4);
+                if (sk.active) {
+                    std::vector<uint16_t> wx((size_t)2 * MTh * KP * PL * 32 * 16, 0);
+                    for (int m2 = 0; m2 < 2 * MTh; m2++)
+                        for (int kp = 0; kp < KP; kp++)
+                            for (int r = 0; r < 32; r++) {
+                                const int mt = m2 % MTh, kind = m2 / MTh;
+                                const int ch = convp_row_logical(kPOutP, mt * 32 + r);
+                                if (ch >= Co) continue;
+                                for (int k = 0; k < 16; k++) {
+                                    const int ci = (2 * kp + k / 8) * 8 + k % 8;
+                                    if (ci >= Co) continue;
+                                    const float x = kind ? rwp[(size_t)ch * Co + ci] : mwp[(size_t)ch * Co + ci];
+                                    const uint16_t h = bf16_rne(x);
+                                    const float r1 = x - bf16_to_f32(h);
+                                    const uint16_t md = bf16_rne(r1);
+                                    const uint16_t parts[3] = {PL == 1 ? f16_rne(x) : h, md, bf16_rne(r1 - bf16_to_f32(md))};
+                                    for (int pln = 0; pln < PL; pln++)
+                                        wx[((((size_t)m2 * KP + kp) * PL + pln) * 32 + r) * 16 + k] = parts[pln];
+                                }
+                            }
+                    if ((rc = dev_alloc(e, sk.wx, (wx.size() + 1) / 2))) return rc;
+                    HIPCHECK(e, hipMemcpy(sk.wx.p, wx.data(), wx.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                    std::vector<float> cst((size_t)6 * Cp, 0.0f);
+                    for (int c = 0; c < Co; c++) {
+                        cst[c] = (*mb)[c]; cst[Cp + c] = (*rb)[c]; cst[2 * Cp + c] = (*nw)[c]; cst[3 * Cp + c] = (*nb)[c];
+                        cst[4 * Cp + c] = (*mnw)[c]; cst[5 * Cp + c] = (*mnb)[c];
+                    }
+                    if ((rc = dev_upload(e, sk.cst, cst))) return rc;
+                    SkipPArgs &a = sk.a;
+                    a.C = Co; a.C8 = C8; a.T = T; a.Fr = Fr; a.TF = T * Fr; a.MTh = MTh; a.KP = KP; a.act = e->act;
+                    a.wx = reinterpret_cast<const uint4 *>(sk.wx.p); a.cst = sk.cst.p;
+                    a.x_stream = (long)C8 * PL * T * Fr; a.out_stream = a.x_stream;
+                    a.Fh = Fi; a.Fo = 2 * Fi - 1; a.y_stream = pv.dec_even.a.y_stream; a.eps_mode = e->eps_mode;
+                    sk.KP = KP;
+                    sk.lds = (size_t)2 * MTh * KP * PL * 64 * 16 + (size_t)6 * Cp * 4;
+                    sk.flops = pv.skip.flops;
+                }
+            }
         } else {
             pv.skip.active = pv.skipm.active = false;
         }
@@ -389,6 +459,16 @@ int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, lo
             const long nu = (long)Co * T * Fr;
             const uint4 *res = reinterpret_cast<const uint4 *>(S.xinP[lvl].p);
             const unsigned res_bytes = (unsigned)((size_t)S.slot_elems[lvl] * kRing * 16);
+            if (pv.sk.active) {
+                SkipPArgs a = pv.sk.a;
+                a.x = res + (long)cur * S.slot_elems[lvl];
+                a.ydec = S.decR[j].p;
+                a.sy = sy;
+                a.out = reinterpret_cast<uint4 *>(S.decP[j].p);
+                ProfScope ps(e, "k_skip_p", ("skip" + std::to_string(j)).c_str(), pv.sk.flops * B, st);
+                if (launch_k_skip_p(PL, pv.sk.KP, B, pv.sk.lds, st, a)) return fail(e, SE_ERR_ARG, "no k_skip_p instance for %d planes x %d K steps", PL, pv.sk.KP);
+                HIPCHECK(e, hipGetLastError());
+            } else {
             {
                 ConvPArgs a = pv.skipm.a;
                 a.xbase = res; a.xbytes = res_bytes; a.cur_off = (long)cur * S.slot_elems[lvl]; a.prev_off = -1;
@@ -405,6 +485,7 @@ int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, lo
                 a.bl_nw = e->lv[j].dec_nw.p; a.bl_nb = e->lv[j].dec_nb.p; a.bl_mnw = e->lv[j].dec_mnw.p; a.bl_mnb = e->lv[j].dec_mnb.p;
                 a.bl_sy = sy; a.bl_su = SlabStats{e->skip_stats[j].p, pv.skipm.grid_x, nu, e->eps_mode};
                 if ((rc = launch_conv_p(e, pv.skip, a, st, ("skip" + std::to_string(j)).c_str()))) return rc;
+            }
             }
             xin = reinterpret_cast<const uint4 *>(S.decP[j].p);
             xin_bytes = (size_t)B * ((Co + 7) / 8) * PL * T * Fr * 16;

@@ -278,7 +278,12 @@ struct GruStepArgs {
     int B, H;
 };
 
-__global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) {
+// Up to four independent steps in ONE launch (blockIdx.z selects the argument set): the pipelined path advances layer l of
+// segment n - l for every layer l at once (layer 1 lags one segment behind layer 0, so both halves of a launch have the
+// same shape and no gate pre-activation has to be recomputed), which halves the chain of dependent launches per segment.
+struct GruStepMulti { GruStepArgs a[4]; };
+
+__device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
     __shared__ float red[2][3][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rt = wave & 1, kh = wave >> 1;
@@ -361,6 +366,9 @@ __global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) { gru_step_body(a); }
+__global__ __launch_bounds__(256) void k_gru_step_multi(GruStepMulti m) { gru_step_body(m.a[blockIdx.z]); }
 
 // Second-generation step kernel: the workgroup's W_hh slice (3 gates x 16 hidden units x H, 96 KB at H = 512) is
 // staged ONCE through LDS in the exact lane order the B fragments are consumed (one conflict-free ds_read_b128 per

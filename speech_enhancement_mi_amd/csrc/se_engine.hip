@@ -122,10 +122,11 @@ struct se_engine {
     DevBuf spec_all, mask_all;         // pipelined se_realtime_process: spectra / masked spectra of one chunk of segments
     DevBuf xin[SE_MAX_LEVELS][kRing];  // encoder level inputs (xin[0] = features)
     DevBuf enc_raw[SE_MAX_LEVELS];
-    DevBuf gru_in[kRing], gi, seq[2], hbuf[4][2], fc_out, dec_in[kRing];
+    DevBuf gru_in[kRing], gi0[kRing], gil[4], seqr[4][kRing], hbuf[4][2], fc_out, dec_in[kRing];  // gi0 / seqr cross stage streams: rings
     int pipeline = 1;                  // SE_PIPELINE=0: one stream, stages back to back
-    hipStream_t stage_stream[3]{};     // encoder / bottleneck / decoder
+    hipStream_t stage_stream[3]{};      // encoder (+ GRU input projection) / decoder (fc + norm first) / recurrence (all layers)
     hipEvent_t ev_enc[kRing]{}, ev_gru[kRing]{}, ev_dec[kRing]{}, ev_fork{}, ev_join{};
+    int gru_lag = 1;                    // SE_GRU_LAG=0: layers back to back on the recurrence stream (NL * T launches per segment)
     bool stage_ready = false;
     int hcur[4]{};
     DevBuf dec_raw[SE_MAX_LEVELS], dec_uv[SE_MAX_LEVELS], dec_out[SE_MAX_LEVELS];
@@ -137,6 +138,9 @@ struct se_engine {
     struct se_convp_state *cp = nullptr;
     int path = 1;
     bool use_p = false;
+    int dbg_skip = 0;         // SE_DBG_SKIP bit mask, TIMING EXPERIMENTS ONLY (results are wrong): 1 = no GRU step launches, 2 = no bottleneck
+                              // GEMMs, 4 = no encoder convolutions, 8 = no decoder
+    int skip_stream = 1;      // SE_SKIP_STREAM=0: decoder skip gate as two k_conv_p launches instead of the streaming k_skip_p
 
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
@@ -790,53 +794,106 @@ int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, lon
 uint4 *decin_p(se_engine *e, int slot);  // convp_engine.inc.h: decoder-input ring slot of the plane path
 
 // Stage 2: the recurrent bottleneck (CRN.py:476-481, 256-282)  gru_in[cur] -> dec_in[cur]
-// `overlapped`: the stage shares the chip with the encoder / decoder streams.  The GRU step then uses the small-footprint
-// kernel (k_gru_step: 54 VGPRs, 6 KB LDS, W_hh straight from L2) whose waves fit next to two resident convolution
-// workgroups, instead of k_gru_step2 (188 VGPRs, 96 KB LDS slice of W_hh), which is 15 % faster alone but has to wait for
-// a convolution workgroup to retire on every CU at every one of the 2 x T steps (measured: 126k vs 119k frames/s).
-int stage_bottleneck(se_engine *e, int cur, hipStream_t st, bool overlapped = false) {
-    const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+// The bottleneck is cut where its data dependencies are (CRN.py:256-282):
+//   stage_gru_proj0  x W_ih0^T for all T frames: depends only on the encoder output, so it runs on the ENCODER stream
+//   stage_gru_layer  layer l: (l > 0: input projection of layer l-1's sequence) + T dependent step launches; each layer has
+//                    its own stream in the pipelined path - layer 1 of segment n runs beside layer 0 of segment n+1
+//   stage_gru_out    fc_output_layer + activation + gLN(last): depends only on the last layer's sequence: DECODER stream
+// so the chain of dependent launches per segment is T steps (+ one GEMM) per stream instead of 2 T + 3 GEMMs on one stream.
+// `overlapped`: the stage shares the chip with the other streams.  The GRU step then uses the small-footprint kernel
+// (k_gru_step: 54 VGPRs, 6 KB LDS, W_hh straight from L2) whose waves fit next to resident convolution workgroups, instead
+// of k_gru_step2 (188 VGPRs, 96 KB LDS slice of W_hh), which is 15 % faster alone but has to wait for a convolution
+// workgroup to retire on every CU at every step.
+int stage_gru_proj0(se_engine *e, int cur, hipStream_t st) {
+    const int T = e->T, B = e->B, H = e->H, D = e->D;
+    if (e->dbg_skip & 2) return 0;
+    return launch_gemm(e, e->gru_in[cur].p, D, e->wih[0].p, D, e->bih[0].p, e->gi0[cur].p, 3L * H, B * T, 3 * H, D, 0, st, "gru_ih0", e->wih_x[0].p);
+}
+
+int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlapped) {
+    const int T = e->T, B = e->B, H = e->H;
     int rc;
-    const float *layer_in = e->gru_in[cur].p;
-    long in_dim = D;
-    for (int l = 0; l < e->NL; l++) {
-        if ((rc = launch_gemm(e, layer_in, in_dim, e->wih[l].p, in_dim, e->bih[l].p, e->gi.p, 3L * H, B * T, 3 * H, (int)in_dim, 0, st, ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
-        float *seq = e->seq[l & 1].p;
-        const int ngroup = (B + 31) / 32, nhid = (H + 15) / 16;
-        const bool use_seq = e->gru_seq && e->gru_direct <= 0 && (H == 512 || H == 128) && nhid <= 256;
-        if (use_seq) {
-            // groups per launch: all workgroups of a launch must be able to become resident (<= 256 CUs, one per CU)
-            const int gmax = std::max(1, 256 / nhid);
-            for (int g0 = 0; g0 < ngroup; g0 += gmax) {
-                const int ng = std::min(gmax, ngroup - g0), rows0 = g0 * 32, rows = std::min(B - rows0, ng * 32);
-                const int hc = e->hcur[l];
-                HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 64 * sizeof(unsigned), st));
-                GruSeqArgs g{e->gi.p + (long)rows0 * T * 3 * H, e->hbuf[l][hc].p + (long)rows0 * H, e->hbuf[l][hc].p + (long)rows0 * H,
-                             e->hbuf[l][hc ^ 1].p + (long)rows0 * H, e->whh[l].p, e->bhh[l].p, seq + (long)rows0 * T * H,
-                             reinterpret_cast<unsigned *>(e->gru_sync.p), reinterpret_cast<unsigned *>(e->gru_sync.p) + 64, rows, H, T};
-                ProfScope ps(e, "k_gru_seq", "gru_seq", 2.0 * rows * 3 * H * H * T, st);
-                if (H == 512) hipLaunchKernelGGL(k_gru_seq<16>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
-                else hipLaunchKernelGGL(k_gru_seq<4>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
-            }
-            if (T & 1) e->hcur[l] ^= 1;  // the last step (t = T-1) wrote P1 when T is odd, P0 when even
-        } else
-        for (int t = 0; t < T; t++) {
+    const float *gi = e->gi0[cur].p;
+    if (l > 0) {
+        gi = e->gil[l].p;
+        if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[l - 1][cur].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
+                                                      ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
+    }
+    float *seq = e->seqr[l][cur].p;
+    const int ngroup = (B + 31) / 32, nhid = (H + 15) / 16;
+    const bool use_seq = e->gru_seq && e->gru_direct <= 0 && (H == 512 || H == 128) && nhid <= 256;
+    if (use_seq) {
+        // groups per launch: all workgroups of a launch must be able to become resident (<= 256 CUs, one per CU)
+        const int gmax = std::max(1, 256 / nhid);
+        for (int g0 = 0; g0 < ngroup; g0 += gmax) {
+            const int ng = std::min(gmax, ngroup - g0), rows0 = g0 * 32, rows = std::min(B - rows0, ng * 32);
             const int hc = e->hcur[l];
-            GruStepArgs g{e->gi.p + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
-                          e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
-            ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
-            const dim3 grid((H + 15) / 16, (B + 31) / 32);
-            const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : overlapped;
-            if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
-            else if (H == 128 && !direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
-            else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
+            HIPCHECK(e, hipMemsetAsync(e->gru_sync.p, 0, 64 * sizeof(unsigned), st));
+            GruSeqArgs g{gi + (long)rows0 * T * 3 * H, e->hbuf[l][hc].p + (long)rows0 * H, e->hbuf[l][hc].p + (long)rows0 * H,
+                         e->hbuf[l][hc ^ 1].p + (long)rows0 * H, e->whh[l].p, e->bhh[l].p, seq + (long)rows0 * T * H,
+                         reinterpret_cast<unsigned *>(e->gru_sync.p), reinterpret_cast<unsigned *>(e->gru_sync.p) + 64, rows, H, T};
+            ProfScope ps(e, "k_gru_seq", "gru_seq", 2.0 * rows * 3 * H * H * T, st);
+            if (H == 512) hipLaunchKernelGGL(k_gru_seq<16>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
+            else hipLaunchKernelGGL(k_gru_seq<4>, dim3(nhid, ng), dim3(256), (size_t)192 * H, st, g);
+        }
+        if (T & 1) e->hcur[l] ^= 1;  // the last step (t = T-1) wrote P1 when T is odd, P0 when even
+    } else
+    for (int t = 0; t < T && !(e->dbg_skip & 1); t++) {
+        const int hc = e->hcur[l];
+        GruStepArgs g{gi + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
+                      e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
+        ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
+        const dim3 grid((H + 15) / 16, (B + 31) / 32);
+        const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : overlapped;
+        if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
+        else if (H == 128 && !direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
+        else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
+        e->hcur[l] = hc ^ 1;
+    }
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+// Pipelined form of the recurrence: ONE stream, layer l works on the segment in ring slot slots[l] (-1: none).  Layer l lags
+// l segments behind layer 0, so the steps of all layers of a round are independent of each other and every time step is ONE
+// launch (k_gru_step_multi, blockIdx.z = layer) instead of one per layer: T dependent launches per segment instead of NL * T.
+int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
+    const int T = e->T, B = e->B, H = e->H;
+    int rc;
+    const float *gi[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nact = 0;
+    for (int l = 0; l < e->NL; l++) {
+        if (slots[l] < 0) continue;
+        nact++;
+        gi[l] = e->gi0[slots[l]].p;
+        if (l > 0) {
+            gi[l] = e->gil[l].p;
+            if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[l - 1][slots[l]].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
+                                                          ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
+        }
+    }
+    if (!nact) return 0;
+    for (int t = 0; t < T && !(e->dbg_skip & 1); t++) {
+        GruStepMulti m{};
+        int z = 0;
+        for (int l = 0; l < e->NL; l++) {
+            if (slots[l] < 0) continue;
+            const int hc = e->hcur[l];
+            m.a[z++] = GruStepArgs{gi[l] + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
+                                   e->hbuf[l][hc ^ 1].p, e->seqr[l][slots[l]].p + (long)t * H, (long)T * H, B, H};
             e->hcur[l] = hc ^ 1;
         }
-        HIPCHECK(e, hipGetLastError());
-        layer_in = seq;
-        in_dim = H;
+        ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H * z, st);
+        hipLaunchKernelGGL(k_gru_step_multi, dim3((H + 15) / 16, (B + 31) / 32, z), dim3(256), 0, st, m);
     }
-    if ((rc = launch_gemm(e, layer_in, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
+int stage_gru_out(se_engine *e, int cur, hipStream_t st) {
+    const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+    int rc;
+    if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
     if (e->use_p) {  // decoder input in the plane layout
         const int PL = operand_planes(e->precision), C = e->Ch[L], C8 = (C + 7) / 8;
         ProfScope ps(e, "k_gln2_p", "gln", 0, st);
@@ -846,6 +903,15 @@ int stage_bottleneck(se_engine *e, int cur, hipStream_t st, bool overlapped = fa
         return 0;
     }
     return launch_gln(e, e->fc_out.p, e->dec_in[cur].p, e->gnw.p, e->gnb.p, (long)T * D, 2, e->Ch[L], T, e->F[L], st);
+}
+
+// single-stream form: all bottleneck stages back to back
+int stage_bottleneck(se_engine *e, int cur, hipStream_t st, bool overlapped = false) {
+    int rc;
+    if ((rc = stage_gru_proj0(e, cur, st))) return rc;
+    for (int l = 0; l < e->NL; l++)
+        if ((rc = stage_gru_layer(e, l, cur, st, overlapped))) return rc;
+    return stage_gru_out(e, cur, st);
 }
 
 // Stage 3: decoder (CRN.py:483-489) + mask application  dec_in[cur], xin[*][cur], spec -> out
@@ -903,9 +969,11 @@ int stage_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long
 namespace {
 
 int run_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
+    if (e->dbg_skip & 4) return 0;
     return e->use_p ? stage_encoder_p(e, cur, prev, spec, sB, sM, sT, sF, st) : stage_encoder(e, cur, prev, spec, sB, sM, sT, sF, st);
 }
 int run_decoder(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long sF, cf2 *out, long oB, long oT, long oF, hipStream_t st) {
+    if (e->dbg_skip & 8) return 0;
     return e->use_p ? stage_decoder_p(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st) : stage_decoder(e, cur, spec, sB, sT, sF, out, oB, oT, oF, st);
 }
 
@@ -1023,6 +1091,9 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_SKIP_FUSE")) e->skip_fuse = atoi(s);
     if (const char *s = getenv("SE_DEC_MERGE")) e->dec_merge = atoi(s);
     if (const char *s = getenv("SE_PATH")) e->path = atoi(s);
+    if (const char *s = getenv("SE_SKIP_STREAM")) e->skip_stream = atoi(s);
+    if (const char *s = getenv("SE_DBG_SKIP")) e->dbg_skip = atoi(s);
+    if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
     e->cp = new se_convp_state();
     {
         int ncu = 0;
@@ -1049,6 +1120,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     aux_set_fft_lds((int)stft_lds_bytes(K, N), (int)istft_lds_bytes(T, N));
     conv_set_attributes();
     conv_p_set_attributes();
+    skip_p_set_attributes();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
@@ -1063,12 +1135,13 @@ void se_destroy(se_engine *e) {
     (void)hipDeviceSynchronize();
     conv_x6_trace_dump();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->maskspec,
-                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->spec_all, &e->mask_all, &e->gi, &e->seq[0], &e->seq[1], &e->fc_out, &e->yseg};
+                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->spec_all, &e->mask_all, &e->fc_out, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
     for (int r = 0; r < kRing; r++) {
-        dev_free(e->spec[r]); dev_free(e->gru_in[r]); dev_free(e->dec_in[r]);
+        dev_free(e->spec[r]); dev_free(e->gru_in[r]); dev_free(e->dec_in[r]); dev_free(e->gi0[r]);
+        for (int l = 0; l < 4; l++) dev_free(e->seqr[l][r]);
         for (int i = 0; i < SE_MAX_LEVELS; i++) dev_free(e->xin[i][r]);
-        if (e->stage_ready) { (void)hipEventDestroy(e->ev_enc[r]); (void)hipEventDestroy(e->ev_gru[r]); (void)hipEventDestroy(e->ev_dec[r]); }
+        if (e->stage_ready) { (void)hipEventDestroy(e->ev_enc[r]); (void)hipEventDestroy(e->ev_dec[r]); (void)hipEventDestroy(e->ev_gru[r]); }
     }
     if (e->stage_ready) {
         (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join);
@@ -1076,7 +1149,7 @@ void se_destroy(se_engine *e) {
     }
     for (int i = 0; i < 4; i++) {
         dev_free(e->wih[i]); dev_free(e->whh[i]); dev_free(e->bih[i]); dev_free(e->bhh[i]); dev_free(e->wih_x[i]);
-        dev_free(e->hbuf[i][0]); dev_free(e->hbuf[i][1]);
+        dev_free(e->hbuf[i][0]); dev_free(e->hbuf[i][1]); dev_free(e->gil[i]);
     }
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
         Level &l = e->lv[i];
@@ -1168,10 +1241,14 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
         if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (e->lv[i].pre.grid_x + 1)))) return rc;
         if ((rc = dev_alloc(e, e->pre_g, nf))) return rc;
     }
-    if ((rc = dev_alloc(e, e->gi, (size_t)B * T * 3 * H)) ||
-        (rc = dev_alloc(e, e->seq[0], (size_t)B * T * H)) || (rc = dev_alloc(e, e->seq[1], (size_t)B * T * H)) ||
-        (rc = dev_alloc(e, e->fc_out, (size_t)B * T * D)))
-        return rc;
+    if ((rc = dev_alloc(e, e->fc_out, (size_t)B * T * D))) return rc;
+    for (int r = 0; r < kRing; r++) {
+        if ((rc = dev_alloc(e, e->gi0[r], (size_t)B * T * 3 * H))) return rc;
+        for (int l = 0; l < e->NL; l++)
+            if ((rc = dev_alloc(e, e->seqr[l][r], (size_t)B * T * H))) return rc;
+    }
+    for (int l = 1; l < e->NL; l++)
+        if ((rc = dev_alloc(e, e->gil[l], (size_t)B * T * 3 * H))) return rc;
     for (int l = 0; l < e->NL; l++)
         for (int p = 0; p < 2; p++) {
             if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
@@ -1406,7 +1483,7 @@ static int ensure_stage_streams(se_engine *e) {
     int least = 0, greatest = 0;
     HIPCHECK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
     for (int k = 0; k < 3; k++)  // the recurrence is a chain of short dependent launches: its waves go first when a CU frees up
-        HIPCHECK(e, hipStreamCreateWithPriority(&e->stage_stream[k], hipStreamNonBlocking, k == 1 ? greatest : least));
+        HIPCHECK(e, hipStreamCreateWithPriority(&e->stage_stream[k], hipStreamNonBlocking, k == 2 ? greatest : least));
     for (int r = 0; r < kRing; r++) {
         HIPCHECK(e, hipEventCreateWithFlags(&e->ev_enc[r], hipEventDisableTiming));
         HIPCHECK(e, hipEventCreateWithFlags(&e->ev_gru[r], hipEventDisableTiming));
@@ -1468,42 +1545,67 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         // Segments are sequentially dependent only WITHIN a stage (conv history, GRU state), so the three stages run as a
         // software pipeline over segments on three streams: while the bottleneck of segment n walks its 2 x T dependent
         // GRU launches, the encoder of n+1.. and the decoder of n-1 keep the matrix cores and HBM busy.
-        hipStream_t sE = e->stage_stream[0], sG = e->stage_stream[1], sD = e->stage_stream[2];
+        hipStream_t sE = e->stage_stream[0], sD = e->stage_stream[1], sG = e->stage_stream[2];
         const long F = e->F[0], T = e->T, M = e->M;
         const size_t spec_n = (size_t)e->B * M * T * F * 2, mask_n = (size_t)e->B * T * F * 2;
         // The STFT of kFftSub segments is one launch on the encoder stream ahead of their encoders, the iSTFT one launch on
-        // the decoder stream behind their decoders: both overlap with the other stages of neighbouring segments.  (The FFT
-        // kernels are safe next to the MFMA kernels since they are built without packed-FP32 instructions, se_aux.hip.)
+        // the decoder stream behind their decoders: both overlap with the other stages of neighbouring segments.
         const long CH = std::min<long>(Nseg, kPipeChunk);
         if ((rc = dev_alloc(e, e->spec_all, spec_n * CH)) || (rc = dev_alloc(e, e->mask_all, mask_n * CH))) return rc;
+        // layer l of a recurrence round works on segment (round - l); SE_GRU_DIRECT=0 pins the LDS-slice step kernel, which has
+        // no multi-layer form: layers then run back to back
+        const bool lagged = e->gru_lag && e->gru_direct != 0 && !e->gru_seq;
+        const int NL = e->NL, lag = lagged ? NL - 1 : 0;
         for (long c0 = 0; c0 < Nseg; c0 += CH) {
             const long cn = std::min(CH, Nseg - c0);
             HIPCHECK(e, hipEventRecord(e->ev_fork, st));
             for (hipStream_t q : e->stage_stream) HIPCHECK(e, hipStreamWaitEvent(q, e->ev_fork, 0));
-            for (long i = 0; i < cn; i++) {
-                const int prev = e->slot, cur = (prev + 1) % kRing;
-                e->slot = cur;
-                const cf2 *spec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * i);
-                cf2 *ms = reinterpret_cast<cf2 *>(e->mask_all.p + mask_n * i);
-                if (i % kFftSub == 0) {
-                    const long ns = std::min<long>(kFftSub, cn - i);
-                    if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, (c0 + i) * P - P - lead, length, e->B * (int)M,
-                                          reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, sE, (int)ns, P, (long)(spec_n / 2)))) return rc;
+            const int slot0 = e->slot;  // segment i of this chunk lives in ring slot (slot0 + 1 + i) % kRing
+            auto slot_of = [&](long i) { return (int)((slot0 + 1 + i) % kRing); };
+            for (long i = 0; i < cn + lag; i++) {
+                if (i < cn) {  // ---- encoder stream: STFT batch, features + encoder, GRU input projection of segment i ----
+                    const int cur = slot_of(i), prev = slot_of(i - 1);
+                    e->slot = cur;
+                    const cf2 *spec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * i);
+                    if (i % kFftSub == 0) {
+                        const long ns = std::min<long>(kFftSub, cn - i);
+                        if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, (c0 + i) * P - P - lead, length, e->B * (int)M,
+                                              reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, sE, (int)ns, P, (long)(spec_n / 2)))) return rc;
+                    }
+                    if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
+                    if ((rc = run_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
+                    if ((rc = stage_gru_proj0(e, cur, sE))) return rc;
+                    HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
+                    HIPCHECK(e, hipStreamWaitEvent(sG, e->ev_enc[cur], 0));
                 }
-                if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
-                if ((rc = run_encoder(e, cur, prev, spec, M * T * F, T * F, F, 1, sE))) return rc;
-                HIPCHECK(e, hipEventRecord(e->ev_enc[cur], sE));
-                HIPCHECK(e, hipStreamWaitEvent(sG, e->ev_enc[cur], 0));
-                if ((rc = stage_bottleneck(e, cur, sG, /*overlapped=*/true))) return rc;
-                HIPCHECK(e, hipEventRecord(e->ev_gru[cur], sG));
-                HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[cur], 0));
-                if ((rc = run_decoder(e, cur, spec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
-                if (i % kFftSub == kFftSub - 1 || i == cn - 1) {
-                    const long i0 = i - i % kFftSub;
+                // ---- recurrence stream ----
+                long done = -1;  // segment whose last layer completes in this round
+                if (lagged) {
+                    int slots[4] = {-1, -1, -1, -1};
+                    for (int l = 0; l < NL; l++)
+                        if (i - l >= 0 && i - l < cn) slots[l] = slot_of(i - l);
+                    if ((rc = stage_gru_round(e, slots, sG))) return rc;
+                    done = i - (NL - 1);
+                } else {
+                    for (int l = 0; l < NL; l++)
+                        if ((rc = stage_gru_layer(e, l, slot_of(i), sG, /*overlapped=*/true))) return rc;
+                    done = i;
+                }
+                if (done < 0 || done >= cn) continue;
+                // ---- decoder stream: fc + norm, decoder, mask, iSTFT batch of segment `done` ----
+                const int dcur = slot_of(done);
+                HIPCHECK(e, hipEventRecord(e->ev_gru[dcur], sG));
+                HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[dcur], 0));
+                const cf2 *dspec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * done);
+                cf2 *ms = reinterpret_cast<cf2 *>(e->mask_all.p + mask_n * done);
+                if ((rc = stage_gru_out(e, dcur, sD))) return rc;
+                if ((rc = run_decoder(e, dcur, dspec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
+                if (done % kFftSub == kFftSub - 1 || done == cn - 1) {
+                    const long i0 = done - done % kFftSub;
                     if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i0), T * F, F, 1, e->B,
-                                           e->yseg.p + (c0 + i0) * K, Nseg * K, sD, (int)(i - i0 + 1), (long)(mask_n / 2), K))) return rc;
+                                           e->yseg.p + (c0 + i0) * K, Nseg * K, sD, (int)(done - i0 + 1), (long)(mask_n / 2), K))) return rc;
                 }
-                HIPCHECK(e, hipEventRecord(e->ev_dec[cur], sD));
+                HIPCHECK(e, hipEventRecord(e->ev_dec[dcur], sD));
             }
             for (hipStream_t q : e->stage_stream) {  // the last decoder implies every earlier stage, but the join costs nothing
                 HIPCHECK(e, hipEventRecord(e->ev_join, q));
@@ -1593,7 +1695,7 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
         if (idx == 1) {
             const int D = e->D, H = e->H;
             if ((rc = dev_alloc(e, tmp, (size_t)B * T * D))) return rc;
-            if ((rc = launch_gemm(e, e->seq[(e->NL - 1) & 1].p, H, e->fcw.p, H, e->fcb.p, tmp.p, D, B * T, D, H, 0, st, "tap_ft", e->fcw_x.p))) { dev_free(tmp); return rc; }
+            if ((rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, tmp.p, D, B * T, D, H, 0, st, "tap_ft", e->fcw_x.p))) { dev_free(tmp); return rc; }
             return finish(e->Ch[L], e->F[L], true);
         }
         const int j = idx - 2, lvl = L - 1 - j;
