@@ -168,6 +168,34 @@ int se_loss_sisnr_fwd(const float *separated, const float *source, const int64_t
 int se_loss_sisnr_bwd(const float *separated, const float *source, const int64_t *lens, int batch, int64_t length, const double *stats,
                       const float *gscale, float *grad, void *stream);
 
+/* ---- training-step building blocks (reference train.py:195-204 = torch autograd over CRN.py:290-401, 196-287) --
+ * fp32-exact MFMA kernels on device tensors; activations are [B][C][T][F] (F innermost).  The Python side
+ * (speech_enhancement_mi_amd/train_ops.py) wires them into torch.autograd.Function objects; torch autograd is the checker.
+ * All calls enqueue on `stream` and return 0 or a negative se_status; se_train_last_error() gives the message. */
+typedef struct {
+    int32_t ntap, CC, nchunk, CoPad, FP;   /* weights are passed pre-arranged as [nchunk][ntap][CC][CoPad] fp32 (zero padded) */
+    int32_t tap_kf[15], tap_kt[15];        /* tap t of that arrangement = reference kernel element (kf, kt) */
+} se_train_conv_layout;
+const char *se_train_last_error(void);
+/* kind 0: TemporalConv2d (CRN.py:314: 5x3, stride (2,1), padding (2,0), dilation (1,d), causal with the history rows `xprev`);
+ * kind 1 / 2: even / odd output-frequency parity of TemporalConvTranspose2d (CRN.py:369, keeping the last T columns).
+ * The input gradient of kind 0 is kinds 1 + 2 applied to dy with the SAME weight tensor (and vice versa): same index algebra. */
+int se_train_conv_layout_query(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil, se_train_conv_layout *out);
+int se_train_conv(int kind, const float *x, const float *xprev, const float *w_arranged, const float *bias, float *y, int B, int Ci, int Co,
+                  int T, int Fi, int Fy, int dil, int act, void *stream);
+/* C[a][b][5][3] = sum_{batch,t,m} G[a][t][m] * S[b][t-(2-kt)d][2m+kf-2]: weight gradient of kind 0 (G = dy, S = x, Sprev = history)
+ * and of the transposed convolution (G = x, S = dy, Sprev = NULL) */
+int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, float *C, int B, int Ca, int Cb, int T, int Fm, int Fs, int dil,
+                        void *stream);
+/* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU); bias may be NULL */
+int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream);
+/* one GRU time step (CRN.py:269 nn.GRU cell), saving r, z, n, gh_n per row in `gates` for the backward pass */
+int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const float *whh, const float *bhh, float *hout, float *seq,
+                      int64_t seq_ld, float *gates, int64_t gates_ld, int B, int H, void *stream);
+/* gate derivatives of one step: dh = d1 + d2 + d3 (NULL = absent) -> dgi, dgh (rows of 3H), dhz = z * dh */
+int se_train_gru_bwd_gates(const float *d1, int64_t d1_ld, const float *d2, const float *d3, const float *gates, int64_t gates_ld, const float *hprev,
+                           int64_t hprev_ld, float *dgi, float *dgh, int64_t dg_ld, float *dhz, int B, int H, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,6 +276,8 @@ struct GruStepArgs {
     float *seq;          // + t*H applied; row stride seq_ld
     long seq_ld;
     int B, H;
+    float *gates;        // training only (nullptr in inference): r, z, n and gh_n of this step, rows of 4H with stride gates_ld,
+    long gates_ld;       // saved for the backward pass (train_ops.inc.h: k_gru_bwd_gates)
 };
 
 // Up to four independent steps in ONE launch (blockIdx.z selects the argument set): the pipelined path advances layer l of
@@ -301,7 +303,7 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
     const float *bp1 = bp0 + (long)H * H;
     const float *bp2 = bp1 + (long)H * H;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    constexpr int PF = 2;  // k blocks in flight
+    constexpr int PF = 4;  // k blocks in flight (depth 8 measured no better: the step is bound by its L2 traffic, not by latency) (each = one L2 round trip of 4 x 16 B per lane; 16 blocks per wave at H = 512)
     float4 qa[PF], q0[PF], q1[PF], q2[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) {
@@ -363,6 +365,10 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
             const float hn = (1.0f - zg) * ng + zg * hp;
             a.hout[(long)row * H + n] = hn;
             a.seq[(long)row * a.seq_ld + n] = hn;
+            if (a.gates) {
+                float *gs = a.gates + (long)row * a.gates_ld;
+                gs[n] = rg; gs[H + n] = zg; gs[2 * H + n] = ng; gs[3 * H + n] = gh_n;
+            }
         }
     }
 }

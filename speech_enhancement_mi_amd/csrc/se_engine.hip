@@ -1846,3 +1846,4 @@ int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap,
 }  // extern "C"
 
 #include "fsn_engine.inc.h"
+#include "train_ops.inc.h"

@@ -1,0 +1,265 @@
+// train_ops.inc.h - hand-written building blocks of the TRAINING step (reference train.py:195-204 runs
+// torch autograd over CRN.py:290-401 / 196-287); included at the end of se_engine.hip, exported through the se_train_* C ABI.
+//
+// What runs where in `TrainableCRN` with use_hip_kernels(True) (speech_enhancement_mi_amd/train_ops.py):
+//   convolution forward            k_conv_igemm (fp32-exact MFMA implicit GEMM, conv_igemm.hip.h) on [B][C][T][F] activations
+//   conv / deconv input gradient   the SAME kernel with the roles swapped: d/dx of the strided causal convolution is the
+//                                  "keep the last T" transposed convolution of dy (and vice versa) - identical index algebra
+//   conv / deconv weight gradient  k_corr_wgrad below: C[a][b][kf][kt] = sum_{batch,t,m} G[a][t][m] * S[b][t-(2-kt)d][2m+kf-2]
+//   dense layers (gi, fc, dW, dx)  k_gemm_tn (fp32-exact MFMA GEMM, gemm.hip.h)
+//   GRU forward step               k_gru_step with the gate values saved for the backward pass
+//   GRU backward step (BPTT)       k_gru_bwd_gates (pointwise gate derivatives) + k_gemm_tn (dh_{t-1} += dgh W_hh)
+// Everything is fp32 with exact MFMA accumulation order (v_mfma_f32_32x32x2_f32 / 16x16x4), so gradients agree with torch
+// autograd to rounding; the checker is tests/test_gpu_round2.py::test_hip_training_ops_vs_autograd.
+
+namespace {
+
+thread_local std::string g_train_error;
+
+int tfail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_train_error = buf;
+    return code;
+}
+
+struct TrainConvGeo {
+    ConvArgs a{};
+    int NT = 0, grid_x = 0;
+    size_t lds = 0;
+    int tap_kf[kMaxTaps]{}, tap_kt[kMaxTaps]{};
+};
+
+// kind 0: TemporalConv2d (5x3, stride (2,1), causal dilated, history rows from xprev)   x [B][Ci][T][Fi] -> y [B][Co][T][Fy=Fo]
+// kind 1 / 2: even / odd output-frequency parity of TemporalConvTranspose2d (keep the last T columns), y [B][Co][T][Fy]
+int train_conv_geometry(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil, TrainConvGeo &g) {
+    std::vector<std::array<int, 4>> taps;
+    int FP, s, os, oo, colpad, tlo_off, St;
+    if (kind == 0) {
+        for (int kf = 0; kf < 5; kf++)
+            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, kt, kf});
+        FP = Fy; s = 2; os = 1; oo = 0; colpad = 2; tlo_off = -2 * dil; St = Fi + 4;
+        if (Fy != (Fi - 1) / 2 + 1) return tfail(SE_ERR_ARG, "strided conv: Fy must be (Fi-1)/2+1");
+    } else if (kind == 1) {
+        for (int kf = 0; kf < 5; kf += 2)
+            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, 2 - kt, 2 - kf / 2});
+        FP = (Fy + 1) / 2; s = 1; os = 2; oo = 0; colpad = 1; tlo_off = 0; St = Fi + 2;
+    } else if (kind == 2) {
+        for (int kf = 1; kf < 5; kf += 2)
+            for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, 2 - kt, 1 + (3 - kf) / 2});
+        FP = Fy / 2; s = 1; os = 2; oo = 1; colpad = 1; tlo_off = 0; St = Fi + 2;
+    } else return tfail(SE_ERR_ARG, "unknown conv kind %d", kind);
+    if (kind != 0 && (Fy < 2 * Fi - 1 || Fy > 2 * Fi)) return tfail(SE_ERR_ARG, "transposed conv: Fy must be 2 Fi - 1 or 2 Fi");
+    const int ntap = (int)taps.size(), ngroup = 3;
+    const int P = T * FP, tiles = (P + 31) / 32;
+    const int CoPad = (Co + 31) / 32 * 32;
+    if (CoPad > 128 || CoPad == 96) return tfail(SE_ERR_ARG, "%d output channels unsupported (32, 64 or 128 GEMM rows)", Co);
+    const int MT = CoPad / 32, NCG = 4 / MT;
+    const int CiPad = (Ci + 1) / 2 * 2;
+    int tpw = 0, NT = 0, n_wg = 0, grouped = 0, Rmax = 0, CC = 0;
+    auto bytes = [&](int cc) { return sizeof(float) * ((size_t)ntap * cc * CoPad + (size_t)cc * Rmax * St); };
+    auto fits = [&](int cc) {
+        return bytes(cc) <= 48 * 1024 && (size_t)cc * Rmax * St <= 256 * kPatchPerThread && (size_t)ntap * cc * CoPad <= 256 * 4 * kWeightPerThread;
+    };
+    bool ok = false;
+    for (int ntmax = 4; ntmax >= 1 && !ok; ntmax--) {  // fewer tiles per workgroup = fewer patch rows, until a 2-channel chunk fits
+        n_wg = (tiles + NCG * ntmax - 1) / (NCG * ntmax);
+        tpw = (tiles + n_wg - 1) / n_wg;
+        NT = (tpw + NCG - 1) / NCG;
+        int rows_pos = (tpw * 32 + FP - 1) / FP + 1;
+        if (rows_pos > T) rows_pos = T;
+        grouped = ngroup * rows_pos < rows_pos + (ngroup - 1) * dil;
+        Rmax = grouped ? ngroup * rows_pos : rows_pos + (ngroup - 1) * dil;
+        CC = CiPad;
+        while (CC > 2 && !fits(CC)) CC -= 2;
+        ok = fits(CC);
+    }
+    if (!ok) return tfail(SE_ERR_ARG, "conv chunk does not fit the staging registers (Fi %d, dilation %d)", Fi, dil);
+    int nchunk = (CiPad + CC - 1) / CC;
+    CC = ((CiPad + nchunk - 1) / nchunk + 1) / 2 * 2;
+    nchunk = (CiPad + CC - 1) / CC;
+    ConvArgs &a = g.a;
+    a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP; a.Fy = Fy;
+    a.s = s; a.os = os; a.oo = oo; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.grouped = grouped;
+    a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.tiles_per_wg = tpw; a.St = St;
+    a.relu_lo = 0; a.relu_hi = 0; a.act = 0; a.gate_pairs = 0; a.Cy = Co; a.cy0 = 0; a.par_rows = 0; a.gatew = nullptr;
+    a.stats = nullptr; a.blend = 0;
+    for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; g.tap_kf[t] = taps[t][0]; g.tap_kt[t] = taps[t][1]; }
+    g.NT = NT; g.grid_x = n_wg; g.lds = bytes(CC);
+    return 0;
+}
+
+}  // namespace
+
+namespace se {
+
+// C[a][b][kf][kt] += sum over (batch, t, m) of G[a][t][m] * S[b][t - (2 - kt) d][2 m + kf - 2]   (rows t' < 0 from Sprev, or zero)
+//   weight gradient of the strided convolution:   G = dy [B][Co][T][Fo], S = x [B][Ci][T][Fi] (+ history) -> dW [Co][Ci][5][3]
+//   weight gradient of the transposed convolution: G = x [B][Ci][T][Fi], S = dy [B][Co][T][2Fi-1]          -> dW [Ci][Co][5][3]
+// One workgroup = one 32 x 32 tile of C (rows a, columns n = b * 15 + tap) over a slice of the (batch, t) rows; its four waves
+// take rows round-robin, v_mfma_f32_32x32x2_f32 contracts two positions m per step, the waves' tiles are summed through LDS
+// and added to C with float atomics (the host zeroes C first).
+struct WgradArgs {
+    const float *G, *S, *Sprev;
+    float *C;
+    int B, Ca, Cb, T, Fm, Fs, dil, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int a0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int N = a.Cb * 15;
+    const int ai = a0 + l31, n = n0 + l31;
+    const bool a_ok = ai < a.Ca, n_ok = n < N;
+    const int bch = n_ok ? n / 15 : 0, tap = n_ok ? n - bch * 15 : 0, kf = tap / 3, kt = tap - kf * 3;
+    const int toff = -(2 - kt) * a.dil;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    const int nrows = a.B * a.T;
+    const int r0 = blockIdx.z * a.rows_per_split, r1 = min(nrows, r0 + a.rows_per_split);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const int bb = row / a.T, t = row - bb * a.T;
+        const float *gp = a.G + (((long)bb * a.Ca + (a_ok ? ai : 0)) * a.T + t) * a.Fm;
+        int ts = t + toff;
+        const float *sbase = a.S;
+        bool s_ok = n_ok;
+        if (ts < 0) { ts += a.T; sbase = a.Sprev; s_ok = s_ok && a.Sprev != nullptr && ts >= 0; }
+        const float *sp = sbase ? sbase + (((long)bb * a.Cb + bch) * a.T + max(ts, 0)) * a.Fs : a.S;
+        for (int m = 0; m < a.Fm; m += 2) {
+            const int mm = m + kh;
+            const float av = (a_ok && mm < a.Fm) ? gp[mm] : 0.0f;
+            const int f = 2 * mm + kf - 2;
+            const float bv = (s_ok && mm < a.Fm && f >= 0 && f < a.Fs) ? sp[f] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    // D layout: column (n) on the lane, rows (a) = (r & 3) + 8 (r >> 2) + 4 kh in the 16 registers
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && n_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (arow < a.Ca) atomicAdd(a.C + ((long)arow * a.Cb + bch) * 15 + tap, acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]);
+        }
+    }
+}
+
+// Gate derivatives of one GRU step (torch.nn.GRU cell; forward in gemm.hip.h: k_gru_step with `gates` saved):
+//   h = (1 - z) n + z hp ;  n = tanh(gi_n + r ghn) ;  r, z = sigmoid(gi + gh)
+// dh = d1 + d2 + d3 (any of them may be null): the loss gradient of this step's output plus what flows back from step t+1
+// (z_{t+1} dh_{t+1}, written here as `dhz`, and dgh_{t+1} W_hh from the GEMM that follows this kernel).
+struct GruBwdArgs {
+    const float *d1, *d2, *d3;  // [B][H] addends of dh_t (d1 with row stride d1_ld)
+    long d1_ld;
+    const float *gates;         // saved r, z, n, ghn of this step: [B] rows of 4H, row stride gates_ld
+    long gates_ld;
+    const float *hprev;         // [B][H], row stride hprev_ld
+    long hprev_ld;
+    float *dgi, *dgh;           // [B] rows of 3H, row strides dg_ld
+    long dg_ld;
+    float *dhz;                 // [B][H]: z * dh (the direct path into h_{t-1})
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void k_gru_bwd_gates(GruBwdArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.B * a.H) return;
+    const int b = (int)(i / a.H), j = (int)(i - (long)b * a.H);
+    float dh = 0.0f;
+    if (a.d1) dh += a.d1[(long)b * a.d1_ld + j];
+    if (a.d2) dh += a.d2[i];
+    if (a.d3) dh += a.d3[i];
+    const float *g = a.gates + (long)b * a.gates_ld;
+    const float r = g[j], z = g[a.H + j], n = g[2 * a.H + j], ghn = g[3 * a.H + j];
+    const float hp = a.hprev[(long)b * a.hprev_ld + j];
+    const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+    const float da = dn * (1.0f - n * n);
+    const float dzp = dz * z * (1.0f - z);
+    const float drp = da * ghn * r * (1.0f - r);
+    float *gi = a.dgi + (long)b * a.dg_ld, *gh = a.dgh + (long)b * a.dg_ld;
+    gi[j] = drp; gi[a.H + j] = dzp; gi[2 * a.H + j] = da;
+    gh[j] = drp; gh[a.H + j] = dzp; gh[2 * a.H + j] = da * r;
+    a.dhz[i] = dh * z;
+}
+
+}  // namespace se
+
+extern "C" {
+
+const char *se_train_last_error(void) { return g_train_error.c_str(); }
+
+int se_train_conv_layout_query(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil, se_train_conv_layout *out) {
+    if (!out) return tfail(SE_ERR_ARG, "null argument");
+    TrainConvGeo g;
+    int rc = train_conv_geometry(kind, Ci, Co, T, Fi, Fy, dil, g);
+    if (rc) return rc;
+    out->ntap = g.a.ntap; out->CC = g.a.CC; out->nchunk = g.a.nchunk; out->CoPad = g.a.CoPad; out->FP = g.a.FP;
+    for (int t = 0; t < 15; t++) { out->tap_kf[t] = t < g.a.ntap ? g.tap_kf[t] : 0; out->tap_kt[t] = t < g.a.ntap ? g.tap_kt[t] : 0; }
+    return SE_OK;
+}
+
+int se_train_conv(int kind, const float *x, const float *xprev, const float *w_arranged, const float *bias, float *y, int B, int Ci, int Co,
+                  int T, int Fi, int Fy, int dil, int act, void *stream) {
+    if (!x || !w_arranged || !bias || !y || B <= 0) return tfail(SE_ERR_ARG, "null argument");
+    TrainConvGeo g;
+    int rc = train_conv_geometry(kind, Ci, Co, T, Fi, Fy, dil, g);
+    if (rc) return rc;
+    ConvArgs a = g.a;
+    a.x = x; a.xprev = xprev; a.w = w_arranged; a.bias = bias; a.y = y;
+    a.act = act; a.relu_lo = 0; a.relu_hi = act ? Co : 0;
+    conv_set_attributes();
+    if (conv_igemm_launch(a.ntap, g.NT, a.CoPad, dim3(g.grid_x, B), g.lds, static_cast<hipStream_t>(stream), a))
+        return tfail(SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, g.NT);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "conv launch failed");
+}
+
+int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, float *C, int B, int Ca, int Cb, int T, int Fm, int Fs, int dil,
+                        void *stream) {
+    if (!G || !S || !C || B <= 0) return tfail(SE_ERR_ARG, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(C, 0, (size_t)Ca * Cb * 15 * sizeof(float), st) != hipSuccess) return tfail(SE_ERR_HIP, "memset failed");
+    const int nrows = B * T, tiles = ((Cb * 15 + 31) / 32) * ((Ca + 31) / 32);
+    int nsplit = std::max(1, std::min(nrows / 4, (4 * 256 + tiles - 1) / tiles));  // ~4 workgroups per CU over the whole grid
+    const int rows_per_split = (nrows + nsplit - 1) / nsplit;
+    nsplit = (nrows + rows_per_split - 1) / rows_per_split;
+    se::WgradArgs a{G, S, Sprev, C, B, Ca, Cb, T, Fm, Fs, dil, rows_per_split};
+    hipLaunchKernelGGL(se::k_corr_wgrad, dim3((Cb * 15 + 31) / 32, (Ca + 31) / 32, nsplit), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "wgrad launch failed");
+}
+
+int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return tfail(SE_ERR_ARG, "null argument");
+    if (K % 4) return tfail(SE_ERR_ARG, "GEMM inner dimension %d must be a multiple of 4", K);
+    se::GemmArgs g{A, W, bias, C, M, N, K, (long)K, (long)K, (long)N, act};
+    hipLaunchKernelGGL(se::k_gemm_tn, dim3((N + se::kGemmBN - 1) / se::kGemmBN, (M + se::kGemmBM - 1) / se::kGemmBM), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), g);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm launch failed");
+}
+
+int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const float *whh, const float *bhh, float *hout, float *seq,
+                      int64_t seq_ld, float *gates, int64_t gates_ld, int B, int H, void *stream) {
+    if (!gi || !hprev || !whh || !bhh || !hout || !seq || B <= 0 || H <= 0 || H % 16) return tfail(SE_ERR_ARG, "bad argument (H must be a multiple of 16)");
+    se::GruStepArgs g{gi, (long)gi_ld, hprev, whh, bhh, hout, seq, (long)seq_ld, B, H, gates, (long)gates_ld};
+    hipLaunchKernelGGL(se::k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru step launch failed");
+}
+
+int se_train_gru_bwd_gates(const float *d1, int64_t d1_ld, const float *d2, const float *d3, const float *gates, int64_t gates_ld, const float *hprev,
+                           int64_t hprev_ld, float *dgi, float *dgh, int64_t dg_ld, float *dhz, int B, int H, void *stream) {
+    if (!gates || !hprev || !dgi || !dgh || !dhz || B <= 0 || H <= 0) return tfail(SE_ERR_ARG, "null argument");
+    se::GruBwdArgs a{d1, d2, d3, (long)d1_ld, gates, (long)gates_ld, hprev, (long)hprev_ld, dgi, dgh, (long)dg_ld, dhz, B, H};
+    hipLaunchKernelGGL(se::k_gru_bwd_gates, dim3((unsigned)(((long)B * H + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru backward launch failed");
+}
+
+}  // extern "C"

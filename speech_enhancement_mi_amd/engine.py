@@ -22,6 +22,8 @@ EXPORTS = [
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
+    "se_train_last_error", "se_train_conv_layout_query", "se_train_conv", "se_train_conv_wgrad", "se_train_gemm", "se_train_gru_step",
+    "se_train_gru_bwd_gates",
 ]
 
 
@@ -30,6 +32,11 @@ class SeConfig(C.Structure):
                 ("hidden", C.c_int32), ("num_layers", C.c_int32), ("num_inputs", C.c_int32),
                 ("kernel_size", C.c_int32), ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32),
                 ("segment_length", C.c_int32), ("variant", C.c_int32), ("precision", C.c_int32)]
+
+
+class TrainConvLayout(C.Structure):  # se_train_conv_layout
+    _fields_ = [("ntap", C.c_int32), ("CC", C.c_int32), ("nchunk", C.c_int32), ("CoPad", C.c_int32), ("FP", C.c_int32),
+                ("tap_kf", C.c_int32 * 15), ("tap_kt", C.c_int32 * 15)]
 
 
 class FsnConfig(C.Structure):
@@ -90,6 +97,14 @@ def load_library():
     L.fsn_flops_per_frame.restype = C.c_double
     L.se_loss_sisnr_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp]
     L.se_loss_sisnr_bwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, vp]
+    i32, i64 = C.c_int, C.c_int64
+    L.se_train_last_error.restype = C.c_char_p
+    L.se_train_conv_layout_query.argtypes = [i32] * 7 + [C.POINTER(TrainConvLayout)]
+    L.se_train_conv.argtypes = [i32, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
+    L.se_train_conv_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 7 + [vp]
+    L.se_train_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.se_train_gru_step.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp]
+    L.se_train_gru_bwd_gates.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, vp]
     L.se_profile.argtypes = [vp, C.c_int]
     L.se_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     _lib = L

@@ -41,6 +41,13 @@ class TrainableCRN(TemporalCRN):
         self._hop = int(round(c["sample_rate"] / 1000.0 * c["hop_length"]))
         self._nfft = c["n_fft"]
         self._state = None
+        self._hip = False
+
+    def use_hip_kernels(self, flag=True):
+        """True: convolutions, transposed convolutions, the GRU and the dense layers run forward AND backward on the
+        hand-written kernels of csrc/train_ops.inc.h (train_ops.py); False: torch ops + autograd (the checker)."""
+        self._hip = bool(flag)
+        return self
 
     # ---- signal glue (utility.py:312-403, CRN.py:505-520) ----
     def _segment(self, x):
@@ -109,6 +116,56 @@ class TrainableCRN(TemporalCRN):
         Y = torch.complex(m[:, 0] * re[:, 0] - m[:, 1] * im[:, 0], m[:, 1] * re[:, 0] + m[:, 0] * im[:, 0])
         return Y, dict(buf=new_buf, h=h.detach())
 
+    # ---- one segment on the hand-written kernels; activations [B, C, T, F] (F innermost, the engine's layout) ----
+    def _forward_segment_hip(self, X, state):
+        from . import train_ops as K
+        re, im = X.real, X.imag  # [B, M, F, T]
+        ang = torch.atan(im / (re + EPS) + EPS)
+        mag = torch.sqrt(re ** 2 + im ** 2 + 1e-10)
+        x = torch.cat([mag, ang[:, :1] - ang[:, 1:]], dim=1).permute(0, 1, 3, 2).contiguous()  # [B, 5, T, F]
+        residuals = [x]
+        new_buf = []
+        for i, blk in enumerate(self.convlist):
+            prev = state["buf"][i] if state["buf"] is not None else None  # the whole previous input: its last 2d columns are the buffer
+            y = K.conv_block(x, prev, blk.conv.weight, blk.conv.bias, 2 ** i)
+            new_buf.append(x.detach())
+            x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            residuals.append(x)
+        B, C, T, Fq = x.shape
+        seq = x.permute(0, 2, 1, 3).reshape(B, T, C * Fq)  # feature index c * F + f (CRN.py:476-478)
+        g = self.gru.sequence_model
+        hs = []
+        for l in range(g.num_layers):
+            h0 = state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size)
+            seq, hT = K.gru_layer(seq, h0, getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"))
+            hs.append(hT.detach())
+        o = torch.relu(K.linear(seq, self.gru.fc_output_layer.weight, self.gru.fc_output_layer.bias))
+        o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
+        x = o.reshape(B, T, C, Fq).permute(0, 2, 1, 3).contiguous()
+        L = len(self.deconvlist)
+
+        def conv1x1(t, mod):  # [B, C, T, F] x [Co, C, 1, 1] through the GEMM kernel
+            w = mod.weight.reshape(mod.weight.shape[0], -1)
+            return K.linear(t.permute(0, 2, 3, 1), w, mod.bias).permute(0, 3, 1, 2)
+
+        for j, blk in enumerate(self.deconvlist):
+            y = K.deconv_block(x, blk.conv.weight, blk.conv.bias, 2 ** j)
+            y = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            if j < L - 1:
+                res = residuals[-2 - j]
+                if res.shape[3] > y.shape[3]:
+                    y = Fn.pad(y, (0, res.shape[3] - y.shape[3]))
+                elif res.shape[3] < y.shape[3]:
+                    y = y[..., :res.shape[3]]
+                m = torch.sigmoid(_gln(conv1x1(res, blk.residualmask), blk.residualnorm.weight, blk.residualnorm.bias))
+                y = m * torch.relu(conv1x1(res, blk.residual)) + (1.0 - m) * y
+            x = y
+        m = x.clamp(-9.9, 9.9)
+        m = -10.0 * torch.log((10.0 - m) / (10.0 + m))
+        mr, mi = m[:, 0].transpose(1, 2), m[:, 1].transpose(1, 2)  # back to [B, F, T]
+        Y = torch.complex(mr * re[:, 0] - mi * im[:, 0], mi * re[:, 0] + mr * im[:, 0])
+        return Y, dict(buf=new_buf, h=hs)
+
     def realtime_process_train(self, mixture, flag=False):
         """Differentiable realtime_process (CRN.py:560-589): [B, M, L] -> [B, L]."""
         K = self.segment_length
@@ -120,8 +177,9 @@ class TrainableCRN(TemporalCRN):
         X = self._stft(seg)  # [B, M, N, F, T]
         outs = []
         state = self._state
+        seg_fn = self._forward_segment_hip if self._hip else self._forward_segment
         for n in range(X.shape[2]):
-            Y, state = self._forward_segment(X[:, :, n], state)
+            Y, state = seg_fn(X[:, :, n], state)
             outs.append(self._istft(Y))
         self._state = state
         y = torch.stack(outs, dim=1)  # [B, N, K]
@@ -170,9 +228,10 @@ class FlatBucket:
         return norm
 
 
-def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1):
+def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr"):
     """One optimizer step of the reference trainer (train.py:195-204) under data parallelism: `accum` micro-batches of local
-    utterances, one flat all-reduce, clip 5, Adam."""
+    utterances, one flat all-reduce, clip 5, Adam.  loss = "full": 0.7 * stoi_loss + 0.3 * (-SI-SNR) (compute_loss,
+    CRN.py:609-611); "sisnr": the SI-SNR term alone."""
     bucket.zero()
     total = 0.0
     chunks = mixture.chunk(accum)
@@ -180,9 +239,13 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
         src = source.chunk(accum)[i]
         ln = None if length is None else length.chunk(accum)[i]
         pred = model.realtime_process_train(mix)
-        loss = si_snr_loss(pred, src, ln) / accum
-        loss.backward()
-        total += float(loss.detach())
+        if loss == "full":
+            lens = ln if ln is not None else torch.full((mix.shape[0],), mix.shape[-1], dtype=torch.int64)
+            val = model.compute_loss(src, pred, lens)[0] / accum
+        else:
+            val = si_snr_loss(pred, src, ln) / accum
+        val.backward()
+        total += float(val.detach())
     bucket.all_reduce_mean()
     bucket.clip_(5.0)
     optimizer.step()

@@ -234,3 +234,112 @@ def test_sisnr_hip_kernels_vs_torch_autograd():
             continue
         assert np.linalg.norm(g[i] - g_ref[i]) <= 2e-3 * np.linalg.norm(g_ref[i]) + 1e-12, i
         assert np.all(g[i, lens[i]:] == 0)
+
+
+# ---- 8f-1: hand-written training kernels (forward + backward) vs torch autograd ---------------------------------------------
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("Ci,Co,Fi,d", [(5, 16, 201, 1), (16, 32, 101, 2), (64, 128, 26, 8), (3, 4, 9, 1)])
+def test_hip_conv_block_vs_autograd(Ci, Co, Fi, d):
+    """TemporalConv2d convolution (CRN.py:314,327): forward, input gradient (a transposed-convolution launch), weight gradient
+    (k_corr_wgrad) and bias gradient against torch conv2d + autograd, with a non-zero history buffer."""
+    import torch.nn.functional as Fn
+    from speech_enhancement_mi_amd import train_ops as K
+    torch.manual_seed(Ci * 100 + d)
+    B, T = 3, 21
+    x = torch.randn(B, Ci, T, Fi, device="cuda", requires_grad=True)
+    prev = torch.randn(B, Ci, T, Fi, device="cuda")
+    w = (torch.randn(Co, Ci, 5, 3, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(Co, device="cuda", requires_grad=True)
+    y = K.conv_block(x, prev, w, b, d)
+    # reference in the reference's own layout [B, C, F, T]: cat(buffer = last 2d time columns of prev, x) -> conv2d
+    xr = x.detach().clone().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    inp = torch.cat([prev[:, :, -2 * d:].permute(0, 1, 3, 2), xr.permute(0, 1, 3, 2)], dim=-1)
+    yr = Fn.conv2d(inp, wr, br, stride=(2, 1), padding=(2, 0), dilation=(1, d)).permute(0, 1, 3, 2)
+    assert y.shape == yr.shape and _rel(y, yr) < 1e-5
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert _rel(x.grad, xr.grad) < 1e-5 and _rel(w.grad, wr.grad) < 1e-4 and _rel(b.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Ci,Co,Fi,d", [(128, 64, 13, 1), (32, 16, 51, 4), (16, 2, 101, 8), (8, 4, 7, 2)])
+def test_hip_deconv_block_vs_autograd(Ci, Co, Fi, d):
+    """TemporalConvTranspose2d convolution keeping the last T columns (CRN.py:369,383) against conv_transpose2d + autograd."""
+    import torch.nn.functional as Fn
+    from speech_enhancement_mi_amd import train_ops as K
+    torch.manual_seed(Ci + d)
+    B, T = 2, 21
+    x = torch.randn(B, Ci, T, Fi, device="cuda", requires_grad=True)
+    w = (torch.randn(Ci, Co, 5, 3, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(Co, device="cuda", requires_grad=True)
+    y = K.deconv_block(x, w, b, d)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    yr = Fn.conv_transpose2d(xr.permute(0, 1, 3, 2), wr, br, stride=(2, 1), padding=(2, 0), dilation=(1, d))[..., -T:].permute(0, 1, 3, 2)
+    assert y.shape == yr.shape and _rel(y, yr) < 1e-5
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert _rel(x.grad, xr.grad) < 1e-5 and _rel(w.grad, wr.grad) < 1e-4 and _rel(b.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("In,H,B", [(1664, 512, 4), (104, 16, 3)])
+def test_hip_gru_layer_and_linear_vs_autograd(In, H, B):
+    """One GRU layer over T = 21 steps with a carried state (forward + BPTT) and the fc layer, against nn.GRU / linear autograd."""
+    from speech_enhancement_mi_amd import train_ops as K
+    torch.manual_seed(H)
+    T = 21
+    ref = torch.nn.GRU(In, H, 1, batch_first=True).cuda()
+    x = torch.randn(B, T, In, device="cuda") * 0.5
+    h0 = torch.randn(B, H, device="cuda") * 0.5
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ps = [p.detach().clone().requires_grad_(True) for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    out, hT = K.gru_layer(xa, h0, *ps)
+    out_r, hT_r = ref(xb, h0[None])
+    assert _rel(out, out_r) < 1e-5 and _rel(hT, hT_r[0]) < 1e-5
+    g = torch.randn_like(out_r)
+    out.backward(g)
+    out_r.backward(g)
+    assert _rel(xa.grad, xb.grad) < 2e-5
+    for p, q in zip(ps, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
+        assert _rel(p.grad, q.grad) < 1e-4
+    w, b = torch.randn(37, In, device="cuda", requires_grad=True), torch.randn(37, device="cuda", requires_grad=True)
+    y = K.linear(xa.detach().requires_grad_(True), w, b)
+    yr = torch.nn.functional.linear(x, w.detach(), b.detach())
+    assert _rel(y, yr) < 1e-5
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "full400"])
+def test_train_step_on_gpu_matches_cpu_autograd(cfgname):
+    """BASELINE config 4 on hardware: one training forward/backward (full loss: 0.7 * STOI + 0.3 * (-SI-SNR)) with the
+    hand-written kernels on the GPU against the torch-autograd run of the same model on the CPU: loss and every parameter
+    gradient (<= 1e-4 relative on the whole flat gradient, per tensor <= 2e-3 of the largest tensor norm)."""
+    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN
+    cfg = TINY if cfgname == "tiny" else FULL400
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of(cfg), seed=2).items()}
+    mix, clean = synth.synth_utterances(2, 8000 if cfgname == "tiny" else 4800, 3, seed=81)
+    L = mix.shape[-1]
+    lens = torch.tensor([L, L - 700])
+
+    def run(device, hip):
+        m = TrainableCRN(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(device).use_hip_kernels(hip)
+        bucket = FlatBucket(list(m.parameters()))
+        pred = m.realtime_process_train(torch.from_numpy(mix).to(device))
+        loss = m.compute_loss(torch.from_numpy(clean).to(device), pred, lens.to(device))[0]
+        loss.backward()
+        return float(loss.detach()), bucket.flat.detach().cpu(), [(n, p.grad.detach().cpu()) for n, p in m.named_parameters()]
+
+    l_cpu, g_cpu, named_cpu = run("cpu", False)
+    l_hip, g_hip, named_hip = run("cuda", True)
+    l_gpu, g_gpu, _ = run("cuda", False)
+    assert abs(l_hip - l_cpu) < 1e-4 * max(1.0, abs(l_cpu))
+    assert _rel(g_gpu, g_cpu) < 2e-4                     # torch ops on the GPU vs the CPU: the rounding floor of this comparison
+    assert _rel(g_hip, g_cpu) < 2e-4, _rel(g_hip, g_cpu)  # hand-written kernels vs CPU autograd
+    gmax = max(float(g.norm()) for _, g in named_cpu)
+    for (n, a), (_, b) in zip(named_hip, named_cpu):
+        assert float((a - b).norm()) < 2e-3 * gmax, n
