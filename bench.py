@@ -344,7 +344,7 @@ def bench_train(args, rank, local_rank, world, backend):
         step()
         prof = train_ops.profile_summary()
         train_ops.PROF = None
-        bwd = {k: v for k, v in prof.items() if k in ("k_corr_wgrad", "k_conv_igemm", "k_gemm_tn")}
+        bwd = {k: v for k, v in prof.items() if k in ("k_corr_wgrad", "k_conv_igemm", "k_gemm_skinny")}
         dom = max(bwd, key=lambda k: bwd[k]["ms"])
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -187,7 +187,7 @@ int se_train_conv(int kind, const float *x, const float *xprev, const float *w_a
  * and of the transposed convolution (G = x, S = dy, Sprev = NULL) */
 int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, float *C, int B, int Ca, int Cb, int T, int Fm, int Fs, int dil,
                         void *stream);
-/* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU); bias may be NULL */
+/* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU); bias may be NULL; K % 8 == 0 */
 int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream);
 /* one GRU time step (CRN.py:269 nn.GRU cell), saving r, z, n, gh_n per row in `gates` for the backward pass */
 int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const float *whh, const float *bhh, float *hout, float *seq,

@@ -6,9 +6,9 @@
 //   conv / deconv input gradient   the SAME kernel with the roles swapped: d/dx of the strided causal convolution is the
 //                                  "keep the last T" transposed convolution of dy (and vice versa) - identical index algebra
 //   conv / deconv weight gradient  k_corr_wgrad below: C[a][b][kf][kt] = sum_{batch,t,m} G[a][t][m] * S[b][t-(2-kt)d][2m+kf-2]
-//   dense layers (gi, fc, dW, dx)  k_gemm_tn (fp32-exact MFMA GEMM, gemm.hip.h)
+//   dense layers (gi, fc, dW, dx)  k_gemm_skinny below (fp32-exact MFMA GEMM, 32 x 32 tiles, K split over the four waves)
 //   GRU forward step               k_gru_step with the gate values saved for the backward pass
-//   GRU backward step (BPTT)       k_gru_bwd_gates (pointwise gate derivatives) + k_gemm_tn (dh_{t-1} += dgh W_hh)
+//   GRU backward step (BPTT)       k_gru_bwd_gates (pointwise gate derivatives) + k_gemm_skinny (dh_{t-1} += dgh W_hh)
 // Everything is fp32 with exact MFMA accumulation order (v_mfma_f32_32x32x2_f32 / 16x16x4), so gradients agree with torch
 // autograd to rounding; the checker is tests/test_gpu_round2.py::test_hip_training_ops_vs_autograd.
 
@@ -154,6 +154,73 @@ __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
     }
 }
 
+// C[M][N] = act(A[M][K] W[N][K]^T + bias[N]) for the training step's GEMMs, which are skinny (M = utterances x frames =
+// tens to hundreds of rows, or one of N / K small): one workgroup = one 32 x 32 tile of C, its four waves split K and are
+// summed through LDS, so even M = 4 (one GRU backward step) spreads over N / 32 workgroups x 4 waves instead of the
+// N / 128 workgroups of the 128 x 128-tile k_gemm_tn.  fp32-exact (v_mfma_f32_32x32x2_f32); within an 8-deep k block lane
+// half h contracts k = 4 h .. 4 h + 3 (one 16-byte load per operand per block) - the order of k is free as long as A and W agree.
+struct SkinnyArgs {
+    const float *A, *W, *bias;
+    float *C;
+    int M, N, K, act;
+};
+
+__global__ __launch_bounds__(256) void k_gemm_skinny(SkinnyArgs a) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int nkb = a.K >> 3;                                  // 8-deep k blocks (K % 8 == 0: host pads)
+    const int kb0 = (int)((long)nkb * wave / 4), kb1 = (int)((long)nkb * (wave + 1) / 4);
+    const float *ap = a.A + (long)min(m0 + l31, a.M - 1) * a.K + 4 * kh;
+    const float *wp = a.W + (long)min(n0 + l31, a.N - 1) * a.K + 4 * kh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    constexpr int PF = 4;
+    float4 qa[PF], qw[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int kb = min(kb0 + i, nkb - 1);
+        qa[i] = *reinterpret_cast<const float4 *>(ap + kb * 8);
+        qw[i] = *reinterpret_cast<const float4 *>(wp + kb * 8);
+    }
+    for (int kb = kb0; kb < kb1; kb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const float4 ca = qa[i], cw = qw[i];
+            const float s = kb + i < kb1 ? 1.0f : 0.0f;  // uniform: a slot past the wave's range contributes nothing
+            const int kn = min(kb + i + PF, nkb - 1);
+            qa[i] = *reinterpret_cast<const float4 *>(ap + kn * 8);
+            qw[i] = *reinterpret_cast<const float4 *>(wp + kn * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x * s, cw.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y * s, cw.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z * s, cw.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w * s, cw.w, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {  // D layout: column (n) on the lane, rows (m) = (r & 3) + 8 (r >> 2) + 4 kh
+        const int n = n0 + l31;
+        if (n < a.N) {
+            const float bs = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < a.M) {
+                    float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + bs;
+                    if (a.act == 1) v = fmaxf(v, 0.0f);
+                    a.C[(long)m * a.N + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // Gate derivatives of one GRU step (torch.nn.GRU cell; forward in gemm.hip.h: k_gru_step with `gates` saved):
 //   h = (1 - z) n + z hp ;  n = tanh(gi_n + r ghn) ;  r, z = sigmoid(gi + gh)
 // dh = d1 + d2 + d3 (any of them may be null): the loss gradient of this step's output plus what flows back from step t+1
@@ -239,10 +306,9 @@ int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, floa
 
 int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return tfail(SE_ERR_ARG, "null argument");
-    if (K % 4) return tfail(SE_ERR_ARG, "GEMM inner dimension %d must be a multiple of 4", K);
-    se::GemmArgs g{A, W, bias, C, M, N, K, (long)K, (long)K, (long)N, act};
-    hipLaunchKernelGGL(se::k_gemm_tn, dim3((N + se::kGemmBN - 1) / se::kGemmBN, (M + se::kGemmBM - 1) / se::kGemmBM), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), g);
+    if (K % 8) return tfail(SE_ERR_ARG, "GEMM inner dimension %d must be a multiple of 8 (pad with zeros)", K);
+    se::SkinnyArgs g{A, W, bias, C, M, N, K, act};
+    hipLaunchKernelGGL(se::k_gemm_skinny, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), g);
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm launch failed");
 }
 

@@ -183,13 +183,13 @@ def _gemm(A, W, bias=None, act=0):
     A, W = A.contiguous(), W.contiguous()
     M, K = A.shape
     N = W.shape[0]
-    if K % 4:  # the kernel walks K in 16-byte steps: pad with zeros (weight-gradient GEMMs contract over B*T rows)
-        pad = 4 - K % 4
+    if K % 8:  # the kernel walks K in 8-deep blocks: pad with zeros (weight-gradient GEMMs contract over B*T rows)
+        pad = 8 - K % 8
         A = torch.nn.functional.pad(A, (0, pad))
         W = torch.nn.functional.pad(W, (0, pad))
         K += pad
     out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    with _Timed("k_gemm_tn", 2.0 * M * N * K):
+    with _Timed("k_gemm_skinny", 2.0 * M * N * K):
         _chk(_lib().se_train_gemm(_p(A), _p(W), _p(bias), _p(out), M, N, K, act, _st()))
     return out
 
