@@ -422,6 +422,11 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
             g.y = reinterpret_cast<uint4 *>(S.xinP[i + 1].p) + (long)cur * S.slot_elems[i + 1];
             g.y_stream = (long)g.C8 * PL * T * Fo;
             launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, B), st, g);
+        } else if (e->gemm_p) {  // last level = A operand of the GRU input projection, as split-bf16 planes (k_gemm_p)
+            g.mode = 1;
+            g.y = reinterpret_cast<uint4 *>(e->gruinP[cur].p);
+            g.y_plane = (long)B * T * g.C8 * Fo;
+            launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, B), st, g);
         } else {  // last level feeds the fp32 GEMM of the bottleneck: [T][C*F] rows (gln_ew mode 1 of the first generation)
             GlnEwArgs ge{nullptr, e->gru_in[cur].p, g.w, g.b, g.st, 3, Co, T, Fo, nullptr};
             ge.x = S.encR[i].p;

@@ -257,6 +257,218 @@ __global__ __launch_bounds__(256) void k_gemm_x(GemmX6Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Second-generation split-bf16 GEMM  C = act(A W^T + bias): BOTH operands arrive pre-split (A planes [PL][M][K] written by
+// the producing kernel - k_gln_p for the GRU input, the GRU step's epilogue for the layer outputs; W planes [PL][N][K] from
+// the host), so staging is a pure copy: `buffer_load_dwordx4 ... lds` (LDS-DMA) pieces, no VALU split, no LDS store.
+//
+// Shape of the kernel, and why (measured on the bottleneck GEMMs, M = 5120, N = 1536, K = 2048 / 512, all at PL = 3):
+//   * these GEMMs are bound by the bytes that enter the CUs (64 B/clk/CU through the texture path), not by HBM and not by
+//     the MFMA pipe: 128 x 128 tiles move 1.4 GB per launch for 77 us of MFMA work.  Three 128 x 128 variants (fp32 A split
+//     in the kernel, both operands by LDS-DMA, W fragments straight from L2 into registers) all ran at 29-37 % MFMA
+//     utilisation, ordered exactly by their bytes (1.2 / 1.4 / 2.2 GB -> 205 / 225 / 265 us).
+//   * so the tile is 256 x 128 per CU (the largest that still gives every CU a tile: 240 tiles), 8 waves of 64 x 64 = two
+//     waves per SIMD, so that one wave's DMA issue cost (60-180 cycles per 1-KiB piece) and LDS latency sit under the other
+//     wave's MFMAs; 32-deep K chunks in a two-stage ring (2 x 72 KB at PL = 3): chunk kc + 1 is in flight while chunk kc is
+//     multiplied, one raw s_barrier per chunk.
+//   * LDS image per (operand, plane): [row][4 pieces of 16 B], piece q of row r at slot q ^ ((r >> 2) & 3): the 16-lane
+//     groups of a ds_read_b128 then touch every 16-byte column of every 256-byte bank row once (conflict-free); the LDS-DMA
+//     destination is lane-linear, so the permutation is applied to the SOURCE address.
+//   * workgroup id -> tile is XCD-aware: the eight XCDs (id mod 8) each own a gx x gy block of tiles, so an operand tile is
+//     fetched into as few L2s as possible.
+struct GemmPArgs {
+    const uint4 *Ap;   // [PL][M][K/8] pieces of 8 bf16
+    const uint4 *Wp;   // [PL][N][K/8]
+    long a_plane, w_plane;  // uint4 per plane
+    const float *bias;
+    float *C;
+    int M, N, K;
+    long ldc;
+    int relu;
+    unsigned a_bytes, w_bytes;  // buffer ranges
+    int nrt, nct;      // row / column tiles
+    int gx, gy;        // XCD grid (gx * gy = 8, nrt % gx == 0, nct % gy == 0) or gx = 0: plain row-major tile order
+};
+
+constexpr int kGemmPBM = 256, kGemmPBN = 128;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SE_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#else
+#define SE_DS_READ128(dst, addr, OFF) (void)(addr)
+#endif
+
+template <int PL>
+__global__ __launch_bounds__(512) void k_gemm_p(GemmPArgs a) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) uint4 gl[];  // [stage 2]{A [PL][256 rows][4 pieces], W [PL][128 rows][4 pieces]}
+    constexpr int kPieces = 1536 * PL;           // uint4 per chunk
+    constexpr int kNA = 2 * PL, kNW = PL;        // LDS-DMA instructions per thread per chunk for A / W
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    int rt, ct;
+    if (a.gx) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int br = a.nrt / a.gx, bc = a.nct / a.gy;  // tiles per XCD block
+        rt = (xcd / a.gy) * br + slot / bc;
+        ct = (xcd % a.gy) * bc + slot % bc;
+    } else {
+        rt = blockIdx.x / a.nct;
+        ct = blockIdx.x - rt * a.nct;
+    }
+    const int m0 = rt * kGemmPBM, n0 = ct * kGemmPBN;
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;
+    const int K8 = a.K >> 3, nk = a.K >> 5;
+    // per-thread source offsets of chunk 0 (bytes).  A: slot s = tid + 512 i = (pl * 256 + row) * 4 + qslot (i < 2 PL);
+    // W: slot s = tid + 512 i = (pl * 128 + row) * 4 + qslot (i < PL)
+    unsigned voa[6], vow[3];  // (fixed extents: arrays sized by a template-dependent constant, used with the LDS-DMA builtin
+                              //  inside a lambda, make clang drop the kernel's host stub without a diagnostic)
+#pragma unroll
+    for (int i = 0; i < kNA; i++) {
+        const int s = tid + 512 * i;
+        const int qslot = s & 3, row = (s >> 2) & 255, pl = s >> 10;
+        const long r = min(m0 + row, a.M - 1);
+        voa[i] = (unsigned)(((long)pl * a.a_plane + r * K8 + (qslot ^ ((row >> 2) & 3))) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < kNW; i++) {
+        const int s = tid + 512 * i;
+        const int qslot = s & 3, row = (s >> 2) & 127, pl = s >> 9;
+        const long r = min(n0 + row, a.N - 1);
+        vow[i] = (unsigned)(((long)pl * a.w_plane + r * K8 + (qslot ^ ((row >> 2) & 3))) * 16);
+    }
+    auto stage = [&](int buf, int kc) {
+        // (the resources are built inside the lambda: a captured __amdgpu_buffer_rsrc_t also drops the host stub)
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.Ap), 0, a.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.Wp), 0, a.w_bytes, 0x00020000);
+        const unsigned add = (unsigned)kc * 64;  // 32 bf16 per chunk
+        uint4 *base = gl + buf * kPieces + wave * 64;
+#pragma unroll
+        for (int i = 0; i < kNA; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void *)(base + i * 512), 16, voa[i] + add, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < kNW; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void *)(base + 1024 * PL + i * 512), 16, vow[i] + add, 0, 0, 0);
+    };
+    // LDS byte addresses of this lane's fragments inside one stage: rows wm + l31 / wn + l31 (+ 32 i and the plane as
+    // immediates), K step ks holds pieces 2 ks + half, XOR-swizzled with bits 2-3 of the row (which only l31 contributes to)
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void *)gl;
+    const int sw = (l31 >> 2) & 3;
+    unsigned adA[2], adB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        adA[ks] = lds0 + (unsigned)(((wm + l31) * 4 + ((2 * ks + half) ^ sw)) * 16);
+        adB[ks] = lds0 + (unsigned)((1024 * PL + (wn + l31) * 4 + ((2 * ks + half) ^ sw)) * 16);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][jj][r] = 0.0f;
+    // The LDS reads are inline assembly on purpose: the compiler cannot tell a ds_read of one stage from the LDS-DMA writes
+    // in flight into the other and would drain the DMA queue (s_waitcnt vmcnt(0)) in front of every visible LDS read, which
+    // serialises the ring.  With opaque reads the only waits are the ones written here.
+    auto multiply = [&](const u32x4 (&fa)[2][3], const u32x4 (&fb)[2][3]) {
+        constexpr int P1 = PL > 1 ? 1 : 0, P2 = PL > 2 ? 2 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                f32x16 c = acc[i][jj];
+                if (PL >= 2) {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][P1]), a2 = __builtin_bit_cast(bf16x8, fa[i][P2]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[jj][0]), b1 = __builtin_bit_cast(bf16x8, fb[jj][P1]), b2 = __builtin_bit_cast(bf16x8, fb[jj][P2]);
+                    if (PL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, fa[i][0]), __builtin_bit_cast(f16x8g, fb[jj][0]), c, 0, 0, 0);
+                }
+                acc[i][jj] = c;
+            }
+    };
+#define SE_GEMMP_READ(fa, fb, ks, sb)                               \
+    {                                                               \
+        const unsigned xa = adA[ks] + (sb), xb = adB[ks] + (sb);    \
+        SE_DS_READ128(fa[0][0], xa, 0);                             \
+        SE_DS_READ128(fa[1][0], xa, 2048);                          \
+        SE_DS_READ128(fb[0][0], xb, 0);                             \
+        SE_DS_READ128(fb[1][0], xb, 2048);                          \
+        if constexpr (PL > 1) {                                     \
+            SE_DS_READ128(fa[0][1], xa, 16384);                     \
+            SE_DS_READ128(fa[1][1], xa, 16384 + 2048);              \
+            SE_DS_READ128(fb[0][1], xb, 8192);                      \
+            SE_DS_READ128(fb[1][1], xb, 8192 + 2048);               \
+        }                                                           \
+        if constexpr (PL > 2) {                                     \
+            SE_DS_READ128(fa[0][2], xa, 32768);                     \
+            SE_DS_READ128(fa[1][2], xa, 32768 + 2048);              \
+            SE_DS_READ128(fb[0][2], xb, 16384);                     \
+            SE_DS_READ128(fb[1][2], xb, 16384 + 2048);              \
+        }                                                           \
+    }
+// all fragments of one K step pass through the wait, so no MFMA that consumes them can be scheduled above it
+#define SE_GEMMP_WAIT(CNT, fa, fb)                                                                                             \
+    if constexpr (PL == 1)                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fb[0][0]), "+v"(fb[1][0]));          \
+    else if constexpr (PL == 2)                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                             \
+                     : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fb[0][0]), "+v"(fb[1][0]), "+v"(fa[0][1]), "+v"(fa[1][1]),         \
+                       "+v"(fb[0][1]), "+v"(fb[1][1]));                                                                        \
+    else                                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                             \
+                     : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fb[0][0]), "+v"(fb[1][0]), "+v"(fa[0][1]), "+v"(fa[1][1]),         \
+                       "+v"(fb[0][1]), "+v"(fb[1][1]), "+v"(fa[0][2]), "+v"(fa[1][2]), "+v"(fb[0][2]), "+v"(fb[1][2]))
+    stage(0, 0);
+    for (int kc = 0; kc < nk; kc++) {
+        const int buf = kc & 1;
+        // chunk kc has landed; after the barrier every wave has also finished reading chunk kc - 1, whose stage chunk kc + 1
+        // goes into.  The request is unconditional (past the end it re-requests the last chunk into the stage nobody reads).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(buf ^ 1, min(kc + 1, nk - 1));
+        const unsigned sb = (unsigned)buf * (kPieces * 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+        u32x4 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
+        SE_GEMMP_READ(fa0, fb0, 0, sb)
+        SE_GEMMP_READ(fa1, fb1, 1, sb)
+        if constexpr (PL == 1) { SE_GEMMP_WAIT(4, fa0, fb0); } else if constexpr (PL == 2) { SE_GEMMP_WAIT(8, fa0, fb0); } else { SE_GEMMP_WAIT(12, fa0, fb0); }
+        multiply(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the first K step's MFMAs above the second wait
+        SE_GEMMP_WAIT(0, fa1, fb1);
+        multiply(fa1, fb1);
+#else
+        (void)sb; (void)multiply;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's redundant request lands before the workgroup's LDS is released
+#undef SE_GEMMP_READ
+#undef SE_GEMMP_WAIT
+    float bsj[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) bsj[jj] = a.bias ? a.bias[min(n0 + wn + jj * 32 + l31, a.N - 1)] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int n = n0 + wn + jj * 32 + l31;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) a.C[(long)m * a.ldc + n] = conv_act(acc[i][jj][r] + bsj[jj], a.relu);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One GRU time step for all streams (torch.nn.GRU cell, gate order r,z,n; reference CRN.py:269):
 //   gh = h_prev W_hh^T + b_hh ;  r = s(gi_r + gh_r) ; z = s(gi_z + gh_z) ; n = tanh(gi_n + r * gh_n)
 //   h  = (1 - z) n + z h_prev
@@ -278,6 +490,9 @@ struct GruStepArgs {
     int B, H;
     float *gates;        // training only (nullptr in inference): r, z, n and gh_n of this step, rows of 4H with stride gates_ld,
     long gates_ld;       // saved for the backward pass (train_ops.inc.h: k_gru_bwd_gates)
+    __bf16 *seqp;        // optional: h_t also as split-bf16 planes [PL][rows][H] (the A operand of the next GEMM, k_gemm_p);
+    long seqp_ld, seqp_plane;  // + t*H applied; row stride and plane stride in elements
+    int seqp_pl;         // planes: 3, 2, or 1 (fp16)
 };
 
 // Up to four independent steps in ONE launch (blockIdx.z selects the argument set): the pipelined path advances layer l of
@@ -368,6 +583,18 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
             if (a.gates) {
                 float *gs = a.gates + (long)row * a.gates_ld;
                 gs[n] = rg; gs[H + n] = zg; gs[2 * H + n] = ng; gs[3 * H + n] = gh_n;
+            }
+            if (a.seqp) {
+                __bf16 *sp = a.seqp + (long)row * a.seqp_ld + n;
+                if (a.seqp_pl == 1) {
+                    const _Float16 hv = (_Float16)hn;
+                    sp[0] = __builtin_bit_cast(__bf16, hv);
+                } else {
+                    __bf16 hh, mm, ll;
+                    split3(hn, hh, mm, ll);
+                    sp[0] = hh; sp[a.seqp_plane] = mm;
+                    if (a.seqp_pl == 3) sp[2 * a.seqp_plane] = ll;
+                }
             }
         }
     }
@@ -487,6 +714,18 @@ __global__ __launch_bounds__(256) void k_gru_step2(GruStepArgs a) {
             const float hn = (1.0f - zg) * ng + zg * hp;
             a.hout[(long)row * H + n] = hn;
             a.seq[(long)row * a.seq_ld + n] = hn;
+            if (a.seqp) {
+                __bf16 *sp = a.seqp + (long)row * a.seqp_ld + n;
+                if (a.seqp_pl == 1) {
+                    const _Float16 hv = (_Float16)hn;
+                    sp[0] = __builtin_bit_cast(__bf16, hv);
+                } else {
+                    __bf16 hh, mm, ll;
+                    split3(hn, hh, mm, ll);
+                    sp[0] = hh; sp[a.seqp_plane] = mm;
+                    if (a.seqp_pl == 3) sp[2 * a.seqp_plane] = ll;
+                }
+            }
         }
     }
 }

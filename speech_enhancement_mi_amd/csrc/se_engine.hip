@@ -138,6 +138,11 @@ struct se_engine {
     struct se_convp_state *cp = nullptr;
     int path = 1;
     bool use_p = false;
+    // second-generation bottleneck GEMMs (k_gemm_p): A operands arrive as split-bf16 planes from their producers
+    bool gemm_p = false;      // decided in ensure_ready: plane path active, K dimensions multiples of 32 (SE_GEMM_P=0 disables)
+    int gemm_p_env = 1;
+    DevBuf gruinP[kRing], seqP[4][kRing];  // [PL][B*T][D'] / [PL][B*T][H] bf16 planes
+    DevBuf wih_xp;                          // W_ih0 planes with K in the engine's feature order (k_gemm_p)
     int dbg_skip = 0;         // SE_DBG_SKIP bit mask, TIMING EXPERIMENTS ONLY (results are wrong): 1 = no GRU step launches, 2 = no bottleneck
                               // GEMMs, 4 = no encoder convolutions, 8 = no decoder
     int skip_stream = 1;      // SE_SKIP_STREAM=0: decoder skip gate as two k_conv_p launches instead of the streaming k_skip_p
@@ -716,6 +721,26 @@ int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw
     return 0;
 }
 
+// C = act(A W^T + bias) with both operands as split-bf16 planes ([PL][rows][K] bf16, K % 32 == 0): k_gemm_p
+int launch_gemm_p(se_engine *e, const float *Ap, const float *Wp, const float *bias, float *C, long ldc, int Mr, int Nc, int Kd, int relu,
+                  hipStream_t st, const char *label) {
+    const int PL = operand_planes(e->precision);
+    ProfScope ps(e, "k_gemm_p", label, 2.0 * Mr * Nc * Kd, st);
+    const int nrt = (Mr + kGemmPBM - 1) / kGemmPBM, nct = (Nc + kGemmPBN - 1) / kGemmPBN;
+    int gx = 0, gy = 0;  // XCD blocks: the most square split of the tile grid into 8 equal blocks, if there is one
+    for (int cx : {2, 4, 1, 8})
+        if (!gx && nrt % cx == 0 && nct % (8 / cx) == 0) { gx = cx; gy = 8 / cx; }
+    GemmPArgs g{reinterpret_cast<const uint4 *>(Ap), reinterpret_cast<const uint4 *>(Wp), (long)Mr * Kd / 8, (long)Nc * Kd / 8, bias, C, Mr, Nc, Kd, ldc, relu,
+                (unsigned)((size_t)PL * Mr * Kd * 2), (unsigned)((size_t)PL * Nc * Kd * 2), nrt, nct, gx, gy};
+    const dim3 grid(nrt * nct);
+    const size_t lds = (size_t)2 * 1536 * PL * 16;
+    if (PL == 1) hipLaunchKernelGGL(k_gemm_p<1>, grid, dim3(512), lds, st, g);
+    else if (PL == 2) hipLaunchKernelGGL(k_gemm_p<2>, grid, dim3(512), lds, st, g);
+    else hipLaunchKernelGGL(k_gemm_p<3>, grid, dim3(512), lds, st, g);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+
 int launch_gln(se_engine *e, const float *x, float *y, const float *w, const float *b, long n, int mode, int C, int T,
                int F, hipStream_t st) {
     ProfScope ps(e, "k_gln", "gln", 0, st);
@@ -807,6 +832,7 @@ uint4 *decin_p(se_engine *e, int slot);  // convp_engine.inc.h: decoder-input ri
 int stage_gru_proj0(se_engine *e, int cur, hipStream_t st) {
     const int T = e->T, B = e->B, H = e->H, D = e->D;
     if (e->dbg_skip & 2) return 0;
+    if (e->gemm_p) return launch_gemm_p(e, e->gruinP[cur].p, e->wih_xp.p, e->bih[0].p, e->gi0[cur].p, 3L * H, B * T, 3 * H, D, 0, st, "gru_ih0");
     return launch_gemm(e, e->gru_in[cur].p, D, e->wih[0].p, D, e->bih[0].p, e->gi0[cur].p, 3L * H, B * T, 3 * H, D, 0, st, "gru_ih0", e->wih_x[0].p);
 }
 
@@ -816,8 +842,10 @@ int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlappe
     const float *gi = e->gi0[cur].p;
     if (l > 0) {
         gi = e->gil[l].p;
-        if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[l - 1][cur].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
-                                                      ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
+        if (e->dbg_skip & 2) {}
+        else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][cur].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
+        else if ((rc = launch_gemm(e, e->seqr[l - 1][cur].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
+                                   ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
     }
     float *seq = e->seqr[l][cur].p;
     const int ngroup = (B + 31) / 32, nhid = (H + 15) / 16;
@@ -842,6 +870,10 @@ int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlappe
         const int hc = e->hcur[l];
         GruStepArgs g{gi + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
                       e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
+        if (e->gemm_p) {
+            g.seqp = reinterpret_cast<__bf16 *>(e->seqP[l][cur].p) + (long)t * H;
+            g.seqp_ld = (long)T * H; g.seqp_plane = (long)B * T * H; g.seqp_pl = operand_planes(e->precision);
+        }
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
         const dim3 grid((H + 15) / 16, (B + 31) / 32);
         const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : overlapped;
@@ -868,8 +900,10 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
         gi[l] = e->gi0[slots[l]].p;
         if (l > 0) {
             gi[l] = e->gil[l].p;
-            if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[l - 1][slots[l]].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
-                                                          ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
+            if (e->dbg_skip & 2) {}
+            else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][slots[l]].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
+            else if ((rc = launch_gemm(e, e->seqr[l - 1][slots[l]].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
+                                       ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
         }
     }
     if (!nact) return 0;
@@ -879,8 +913,13 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
         for (int l = 0; l < e->NL; l++) {
             if (slots[l] < 0) continue;
             const int hc = e->hcur[l];
-            m.a[z++] = GruStepArgs{gi[l] + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
-                                   e->hbuf[l][hc ^ 1].p, e->seqr[l][slots[l]].p + (long)t * H, (long)T * H, B, H};
+            GruStepArgs &ga = m.a[z++];
+            ga = GruStepArgs{gi[l] + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
+                             e->hbuf[l][hc ^ 1].p, e->seqr[l][slots[l]].p + (long)t * H, (long)T * H, B, H};
+            if (e->gemm_p) {
+                ga.seqp = reinterpret_cast<__bf16 *>(e->seqP[l][slots[l]].p) + (long)t * H;
+                ga.seqp_ld = (long)T * H; ga.seqp_plane = (long)B * T * H; ga.seqp_pl = operand_planes(e->precision);
+            }
             e->hcur[l] = hc ^ 1;
         }
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H * z, st);
@@ -893,7 +932,9 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
 int stage_gru_out(se_engine *e, int cur, hipStream_t st) {
     const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
     int rc;
-    if (!(e->dbg_skip & 2) && (rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
+    if (e->dbg_skip & 2) {}
+    else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[e->NL - 1][cur].p, e->fcw_x.p, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc"))) return rc; }
+    else if ((rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
     if (e->use_p) {  // decoder input in the plane layout
         const int PL = operand_planes(e->precision), C = e->Ch[L], C8 = (C + 7) / 8;
         ProfScope ps(e, "k_gln2_p", "gln", 0, st);
@@ -1023,6 +1064,18 @@ int ensure_ready(se_engine *e) {
     if (replanned) {
         e->use_p = e->path != 0 && convp_supported(e);
         if (e->use_p && (rc = prepare_weights_p(e))) return rc;
+        e->gemm_p = e->use_p && e->gemm_p_env && !e->gru_seq && e->D % 32 == 0 && e->H % 32 == 0 && e->Ch[e->L] % 8 == 0;
+        if (e->gemm_p) {  // W_ih0 with its K axis in the engine's feature order k' = (o * F + f) * 8 + c  (reference d = (8 o + c) * F + f)
+            const int Fl = e->F[e->L], D = e->D, H = e->H;
+            const std::vector<float> &w = e->params["gru.sequence_model.weight_ih_l0"];
+            std::vector<float> wp((size_t)3 * H * D);
+            for (int r = 0; r < 3 * H; r++)
+                for (int d = 0; d < D; d++) {
+                    const int cabs = d / Fl, f = d - cabs * Fl;
+                    wp[(size_t)r * D + ((size_t)(cabs >> 3) * Fl + f) * 8 + (cabs & 7)] = w[(size_t)r * D + d];
+                }
+            if ((rc = upload_split3(e, e->wih_xp, wp))) return rc;
+        }
         if (e->use_p && e->B > 0) select_all_p(e);
     }
     if (replanned && e->B > 0)  // new weights re-made the plans with their default tiling: restore the per-batch choice
@@ -1094,6 +1147,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_SKIP_STREAM")) e->skip_stream = atoi(s);
     if (const char *s = getenv("SE_DBG_SKIP")) e->dbg_skip = atoi(s);
     if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
+    if (const char *s = getenv("SE_GEMM_P")) e->gemm_p_env = atoi(s);
     e->cp = new se_convp_state();
     {
         int ncu = 0;
@@ -1121,6 +1175,9 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     conv_set_attributes();
     conv_p_set_attributes();
     skip_p_set_attributes();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 1536 * 1 * 16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 1536 * 2 * 16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_p<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 1536 * 3 * 16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_step2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_seq<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 192 * 128);
@@ -1135,10 +1192,11 @@ void se_destroy(se_engine *e) {
     (void)hipDeviceSynchronize();
     conv_x6_trace_dump();
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->maskspec,
-                         &e->gru_sync, &e->fcw_x, &e->pre_g, &e->spec_all, &e->mask_all, &e->fc_out, &e->yseg};
+                         &e->gru_sync, &e->fcw_x, &e->wih_xp, &e->pre_g, &e->spec_all, &e->mask_all, &e->fc_out, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
     for (int r = 0; r < kRing; r++) {
-        dev_free(e->spec[r]); dev_free(e->gru_in[r]); dev_free(e->dec_in[r]); dev_free(e->gi0[r]);
+        dev_free(e->spec[r]); dev_free(e->gru_in[r]); dev_free(e->dec_in[r]); dev_free(e->gi0[r]); dev_free(e->gruinP[r]);
+        for (int l = 0; l < 4; l++) dev_free(e->seqP[l][r]);
         for (int l = 0; l < 4; l++) dev_free(e->seqr[l][r]);
         for (int i = 0; i < SE_MAX_LEVELS; i++) dev_free(e->xin[i][r]);
         if (e->stage_ready) { (void)hipEventDestroy(e->ev_enc[r]); (void)hipEventDestroy(e->ev_dec[r]); (void)hipEventDestroy(e->ev_gru[r]); }
@@ -1249,6 +1307,14 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     }
     for (int l = 1; l < e->NL; l++)
         if ((rc = dev_alloc(e, e->gil[l], (size_t)B * T * 3 * H))) return rc;
+    if (e->gemm_p) {
+        const size_t PLn = operand_planes(e->precision);
+        for (int r = 0; r < kRing; r++) {
+            if ((rc = dev_alloc(e, e->gruinP[r], (PLn * B * T * D + 1) / 2))) return rc;
+            for (int l = 0; l < e->NL; l++)
+                if ((rc = dev_alloc(e, e->seqP[l][r], (PLn * B * T * H + 1) / 2))) return rc;
+        }
+    }
     for (int l = 0; l < e->NL; l++)
         for (int p = 0; p < 2; p++) {
             if ((rc = dev_alloc(e, e->hbuf[l][p], (size_t)B * H))) return rc;
@@ -1647,6 +1713,27 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
             if (count) *count = (int64_t)n;
             if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
             return p_to_host(e, psrc, C, F, host_out, st, true);
+        }
+        if (e->gemm_p && sscanf(name, "enc%d", &idx) == 1 && idx == L - 1) {  // the GRU input lives as GEMM A planes [PL][B*T][(o*F+f)*8+c]
+            const int Cl = e->Ch[L], Fl = e->F[L], PLn = operand_planes(e->precision), D = e->D;
+            const size_t n = (size_t)B * Cl * T * Fl;
+            if (count) *count = (int64_t)n;
+            if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+            std::vector<uint16_t> h((size_t)PLn * B * T * D);
+            HIPCHECK(e, hipStreamSynchronize(st));
+            HIPCHECK(e, hipMemcpy(h.data(), e->gruinP[cur].p, h.size() * 2, hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++)
+                for (int c = 0; c < Cl; c++)
+                    for (int t = 0; t < T; t++)
+                        for (int f = 0; f < Fl; f++) {
+                            float v = 0;
+                            for (int pl = 0; pl < PLn; pl++) {
+                                const uint16_t u = h[((size_t)pl * B * T + (size_t)b * T + t) * D + ((size_t)(c >> 3) * Fl + f) * 8 + (c & 7)];
+                                if (PLn == 1) { _Float16 hv; memcpy(&hv, &u, 2); v += (float)hv; } else v += bf16_to_f32(u);
+                            }
+                            host_out[(((size_t)b * Cl + c) * Fl + f) * T + t] = v;
+                        }
+            return SE_OK;
         }
         idx = -1;  // enc{L-1} (the fp32 GRU input) and unknown names fall through
     }

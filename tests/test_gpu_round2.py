@@ -343,3 +343,23 @@ def test_train_step_on_gpu_matches_cpu_autograd(cfgname):
     gmax = max(float(g.norm()) for _, g in named_cpu)
     for (n, a), (_, b) in zip(named_hip, named_cpu):
         assert float((a - b).norm()) < 2e-3 * gmax, n
+
+
+def test_plane_gemm_matches_first_generation_gemm(monkeypatch):
+    """k_gemm_p (split-bf16 A planes written by the producers, LDS-DMA ring) against k_gemm_x (fp32 A split in the
+    kernel) on the whole bottleneck: same products, different summation grouping -> fp32 round-off only.  Also the
+    'enc{L-1}' tap, which the plane path reconstructs from the GEMM's A planes."""
+    from test_gpu_parity import FULL512, _engine, _cuda, rel_rms
+    mix, _ = synth.synth_utterances(4, 9600, 3, seed=77)
+    x = _cuda(mix)
+    last = "enc%d" % (len(FULL512["num_channels"]) - 1)
+    outs, taps = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SE_GEMM_P", flag)
+        e = _engine(FULL512, seed=9)
+        outs[flag] = e.realtime_process(x).cpu().numpy()
+        e.reset(4)
+        e.step(x[:, :, :3200].contiguous())
+        taps[flag] = np.asarray(e.read_tap(last))
+    assert rel_rms(outs["1"], outs["0"]) < 2e-6
+    assert taps["1"].shape == taps["0"].shape and rel_rms(taps["1"], taps["0"]) < 1e-6
