@@ -19,5 +19,6 @@ cd $R
 python3 profiles/summarize.py stats $out/stats $out/kernel_stats.csv
 python3 profiles/summarize.py pmc $out/pmc_mfma $out/pmc_mfma.csv
 python3 profiles/summarize.py pmc $out/pmc_fetch $out/pmc_write $out/pmc_hbm.csv
+python3 profiles/summarize.py hbm-json $out/pmc_hbm.csv "${WORKLOAD_KEY:-crn/b256/nfft512/f32}" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_run.sh $tag (serial stage order)" $out/pmc_hbm_current.json
 rm -rf $out/stats $out/pmc_mfma $out/pmc_fetch $out/pmc_write
 ls -la $out

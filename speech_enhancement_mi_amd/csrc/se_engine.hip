@@ -727,9 +727,15 @@ int launch_gemm_p(se_engine *e, const float *Ap, const float *Wp, const float *b
     const int PL = operand_planes(e->precision);
     ProfScope ps(e, "k_gemm_p", label, 2.0 * Mr * Nc * Kd, st);
     const int nrt = (Mr + kGemmPBM - 1) / kGemmPBM, nct = (Nc + kGemmPBN - 1) / kGemmPBN;
-    int gx = 0, gy = 0;  // XCD blocks: the most square split of the tile grid into 8 equal blocks, if there is one
-    for (int cx : {2, 4, 1, 8})
-        if (!gx && nrt % cx == 0 && nct % (8 / cx) == 0) { gx = cx; gy = 8 / cx; }
+    // XCD blocks: the split of the tile grid into 8 equal blocks (gx x gy) that fetches the fewest bytes into the 8 private
+    // L2s - every row tile of A is fetched by the gy XCDs of its block row, every column tile of W by gx
+    int gx = 0, gy = 0;
+    double best = 0;
+    for (int cx : {1, 2, 4, 8}) {
+        if (nrt % cx || nct % (8 / cx)) continue;
+        const double bytes = (double)Mr * (8 / cx) + (double)Nc * cx;  // x Kd x bytes per element, common to all candidates
+        if (!gx || bytes < best) { gx = cx; gy = 8 / cx; best = bytes; }
+    }
     GemmPArgs g{reinterpret_cast<const uint4 *>(Ap), reinterpret_cast<const uint4 *>(Wp), (long)Mr * Kd / 8, (long)Nc * Kd / 8, bias, C, Mr, Nc, Kd, ldc, relu,
                 (unsigned)((size_t)PL * Mr * Kd * 2), (unsigned)((size_t)PL * Nc * Kd * 2), nrt, nct, gx, gy};
     const dim3 grid(nrt * nct);
