@@ -303,6 +303,66 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
         }
         return;
     }
+    if (a.out_mode == kPOutPre) {
+        // <= 8 channels: GEMM rows 0-3 / 8-11 are channels 0-7, i.e. registers 0-7 of lane half 0 (half 1 holds padding rows)
+        float *yb = a.y + (long)b * a.y_stream;
+        const int C = a.Cy;
+        const float *gw = a.gatew;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int p = p0 + (cg + i * NCG) * 32 + l31;
+            if (p >= p1 || half) continue;
+            const int t = (int)(((float)p + 0.5f) * invFP), m = p - t * a.FP;
+            float x[8], o[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) x[c] = c < C ? convp_act(acc[i][c] + bv[c], a.act) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                float tr = 0.0f, gt = 0.0f;
+                if (c < C) {
+                    tr = gw[2 * C * C + c];
+                    gt = gw[2 * C * C + C + c];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j < C) { tr += gw[c * C + j] * x[j]; gt += gw[C * C + c * C + j] * x[j]; }
+                }
+                const float v = c < C ? tr * (1.0f / (1.0f + expf(-gt))) : 0.0f;
+                o[c] = v;
+                ssum += v; ssq += v * v;
+            }
+            float4 *dst = reinterpret_cast<float4 *>(yb + ((long)t * a.oT + a.oo + m) * 8);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (a.stats) convp_stats_store(a.stats, a.stats_nslot, a.stats_slot0, ssum, ssq, reinterpret_cast<float *>(planes), b);
+        return;
+    }
+    if (a.out_mode == kPOutGate) {
+        // rows are permuted like the blend epilogue: register pair (2q, 2q+1) of lane half h = (conv_trans, conv_gated) of
+        // channel gate_c0 + mt*16 + h*8 + q; the product goes to the R layout with its statistics for the block's gLN
+        const int c0 = mt * 16 + half * 8;
+        float *yb = a.y + (long)b * a.y_stream + (long)((a.gate_c0 + c0) >> 3) * a.y_npos * 8;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int p = p0 + (cg + i * NCG) * 32 + l31;
+            if (p >= p1 || c0 >= a.Cy) continue;
+            const int t = (int)(((float)p + 0.5f) * invFP), m = p - t * a.FP;
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float u = acc[i][2 * q] + bv[2 * q];
+                const float v = acc[i][2 * q + 1] + bv[2 * q + 1];
+                const float x = (c0 + q < a.Cy) ? u * (1.0f / (1.0f + expf(-v))) : 0.0f;
+                o[q] = x;
+                ssum += x; ssq += x * x;
+            }
+            float4 *dst = reinterpret_cast<float4 *>(yb + ((long)t * a.oT + a.oo + m) * 8);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (a.stats) convp_stats_store(a.stats, a.stats_nslot, a.stats_slot0, ssum, ssq, reinterpret_cast<float *>(planes), b);
+        return;
+    }
     // R layout (or statistics only): register group q = r >> 2 holds rows 8 q + 4 half + {0..3} of M tile mt
     float *yb = a.y ? a.y + (long)b * a.y_stream : nullptr;
 #pragma unroll
@@ -356,6 +416,19 @@ __global__ __launch_bounds__(256) void k_featurize_p(FeatPArgs a) {
     split_store8<PL>(o, a.out + (long)b * a.out_stream + i, TF);
 }
 
+// fp32 [b][C][T*F] with C <= 8 -> octet 0 of the P layout (CRN_ELU / student: the fp32 pre-conv chain hands over here)
+template <int PL>
+__global__ __launch_bounds__(256) void k_f32_to_p(F32ToPArgs a) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.TF) return;
+    const float *x = a.x + (long)b * a.C * a.TF + i;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        if (c < a.C) v[c] = x[(long)c * a.TF];
+    split_store8<PL>(v, a.out + (long)b * a.out_stream + i, a.TF);
+}
+
 // gLN from the producing convolution's partial statistics: R layout -> P layout (normalise, per-channel affine, split)
 
 template <int PL>
@@ -382,6 +455,26 @@ __global__ __launch_bounds__(256) void k_gln_p(GlnPArgs a) {
         float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
 #pragma unroll
         for (int c = 0; c < 8; c++) v[c] = v[c] * sc[c] + sh[c];  // (x - mean) * inv * w + b; zero for padded channels
+        if (a.res) {  // + x: the planes of x, summed from the smallest, give x back exactly
+            const uint4 *rp = a.res + (long)b * a.res_stream + (long)o * PL * TF + i;
+            float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int pl = PL - 1; pl >= 0; pl--) {
+                const uint4 u = rp[(long)pl * TF];
+                if (PL == 1) {
+                    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                    const h8 hv = __builtin_bit_cast(h8, u);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) r[c] += (float)hv[c];
+                } else {
+                    const bf16x8 bv8 = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) r[c] += (float)bv8[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] += r[c];
+        }
         if (a.mode == 0) split_store8<PL>(v, a.y + (long)b * a.y_stream + (long)o * PL * TF + i, TF);
         else split_store8<PL>(v, a.y + ((long)(b * a.T + t) * a.C8 + o) * a.F + f, a.y_plane);
     }

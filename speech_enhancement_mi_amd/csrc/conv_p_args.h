@@ -8,7 +8,7 @@ namespace se {
 constexpr int kPNiMax = 20;   // LDS-DMA instructions per thread per chunk: PL * CO * Npos <= 256 * kPNiMax (host-checked)
 constexpr unsigned kPOob = 0xFFFFFFF0u;  // buffer offset beyond every ring: the bounds check returns zeros
 
-enum ConvPOut : int { kPOutR = 0, kPOutP = 1, kPOutBlend = 2, kPOutStats = 3 };
+enum ConvPOut : int { kPOutR = 0, kPOutP = 1, kPOutBlend = 2, kPOutStats = 3, kPOutGate = 4, kPOutPre = 5 };
 
 struct ConvPArgs {
     // ---- input: P layout, one allocation holding every ring slot ----
@@ -36,6 +36,8 @@ struct ConvPArgs {
     long yp_stream;         // uint4 per stream
     int Fy;                 // row length of the P output; position (t, m) -> column oo + m
     int Cy;                 // channels of the output tensor
+    int gate_c0;            // kPOutGate: rows (2c, 2c+1) = (conv_trans, conv_gated) of channel gate_c0 + c (CRN_ELU.py:223-224,240);
+                            // y[gate_c0 + c] = trans * sigmoid(gated) in the R layout, statistics of the stored values
     // statistics of the stored values (rows [stats_lo, stats_hi)) -> stats[(b*nslot + slot0 + blockIdx.x)*2 + {0,1}]
     float *stats;
     int stats_nslot, stats_slot0, stats_lo, stats_hi;
@@ -43,6 +45,9 @@ struct ConvPArgs {
     int par_rows;           // 1: GEMM rows (2c, 2c+1) = even / odd output-frequency parity of channel c of a transposed convolution
                             // merged into one launch (zero weights where a parity does not use a tap); the odd row of the last
                             // position (m == FP - 1) does not exist and is left out of the statistics
+    const float *gatew;     // kPOutPre (5x5 pre-conv blocks of CRN_ELU, <= 8 channels): [trans Cy x Cy][gated Cy x Cy][trans bias][gated bias];
+                            // GEMM rows 0-3 / 8-11 = channels 0-7, so lane half 0 holds every channel of its position in registers 0-7 and
+                            // the gated 1x1 pair is channel mixing in registers: y = trans(act(conv)) * sigmoid(gated(act(conv))) -> R layout
     // ---- fused decoder skip gate (kPOutBlend): rows (2c, 2c+1) = (residualmask_c, residual_c) ----
     const float *bl_ydec;   // R layout of the transposed convolution of this block: [b][Cy8][T * bl_oT][8]
     long bl_stream;
@@ -59,6 +64,13 @@ struct FeatPArgs {
     int M, T, F, atan2_phase;
 };
 
+struct F32ToPArgs {   // fp32 [b][C][T*F] (C <= 8) -> P layout octet 0: the hand-over from the fp32 pre-conv chain of CRN_ELU
+    const float *x;
+    uint4 *out;
+    long out_stream;  // uint4 per stream
+    int C, TF;
+};
+
 struct GlnPArgs {
     const float *x;     // R layout [b][C8][npos_in][8]
     long x_stream;      // floats per stream
@@ -66,6 +78,8 @@ struct GlnPArgs {
     int in_oT;          // input position of (t, f) = t * in_oT + f
     const float *w, *b; // [C]
     SlabStats st;
+    const uint4 *res;   // optional residual in the P layout of the output (CRN_ELU pre-conv blocks: x = m(x) + x), added after the norm
+    long res_stream;    // uint4 per stream
     uint4 *y;           // mode 0: P[b][o][pl][t][f]   mode 1: A planes of the GRU input GEMM, [pl][b*T + t][o][f] (K = C8*F*8)
     long y_stream;      // mode 0: uint4 per stream
     long y_plane;       // mode 1: uint4 per plane (= B*T*C8*F)

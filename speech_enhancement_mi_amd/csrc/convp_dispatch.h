@@ -11,6 +11,7 @@ bool conv_p_has_instance(int ntap, int NT, int CO);
 void conv_p_set_attributes();
 void launch_k_featurize_p(int PL, dim3 grid, hipStream_t st, const FeatPArgs &a);
 void launch_k_gln_p(int PL, dim3 grid, hipStream_t st, const GlnPArgs &a);
+void launch_k_f32_to_p(int PL, dim3 grid, hipStream_t st, const F32ToPArgs &a);
 void launch_k_gln2_p(int PL, dim3 grid, hipStream_t st, const Gln2PArgs &a);
 void launch_k_final_mask_p(dim3 grid, hipStream_t st, const MaskPArgs &a);
 // k_skip_p<PL, KP> (skip_p.hip.h): one workgroup of 512 threads per stream; 0 = launched, 1 = no such instance

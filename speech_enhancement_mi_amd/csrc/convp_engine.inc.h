@@ -37,6 +37,7 @@ struct SkipPPlan {  // k_skip_p: the whole skip gate of one decoder level, one w
 
 struct PLevel {
     ConvPPlan enc, dec_even, dec_odd, skip, skipm;
+    ConvPPlan gate[2];  // CRN_ELU / student: conv_trans * sigmoid(conv_gated) after the encoder convolution, <= 64 channels per launch
     SkipPPlan sk;
     bool dec_merged = false;
 };
@@ -44,8 +45,9 @@ struct PLevel {
 // GEMM row -> logical row of the caller's weight selector, for the epilogue's register ownership (conv_p.hip.h)
 inline int convp_row_logical(int mode, int row) {
     const int mt = row >> 5, rp = row & 31, h = (rp >> 2) & 1, r = (rp & 3) + 4 * (rp >> 3);
+    if (mode == kPOutPre) return (mt == 0 && h == 0 && r < 8) ? r : (1 << 20);  // channels 0-7 = registers 0-7 of lane half 0
     if (mode == kPOutP) return mt * 32 + 16 * h + r;                       // registers 0..15 of half h = channels 16 h + r
-    if (mode == kPOutBlend) return 2 * (mt * 16 + 8 * h + (r >> 1)) + (r & 1);  // pairs (residualmask, residual) of channel 8 h + r/2
+    if (mode == kPOutBlend || mode == kPOutGate) return 2 * (mt * 16 + 8 * h + (r >> 1)) + (r & 1);  // pairs (residualmask, residual) / (trans, gated) of channel 8 h + r/2
     return row;
 }
 
@@ -56,6 +58,13 @@ struct se_convp_state {
     DevBuf xinP[SE_MAX_LEVELS];   // [kRing][B][C8][PL][T][F] uint4
     long slot_elems[SE_MAX_LEVELS]{};  // uint4 per ring slot
     DevBuf encR[SE_MAX_LEVELS];   // [B][Co8][T*Fo][8]
+    DevBuf encA[SE_MAX_LEVELS];   // CRN_ELU / student: act(conv) in the P layout, the input of the gated 1x1 pair
+    // CRN_ELU / student: the three 5x5 frequency-dilated pre-conv blocks on the plane path (CRN_ELU.py:335-340, 375-376)
+    bool pre_p = false;
+    ConvPPlan pre[3];
+    DevBuf pinP[3];               // block inputs, [kRing][B][1][PL][T][F0] (ring: the previous slot's tail = the 4 history frames)
+    long pslot_elems = 0;         // uint4 per ring slot
+    DevBuf preR, pre_gw[3];       // gated output of a block, R layout [B][1][T*F0][8]; gate weights of each block
     DevBuf decinP[kRing];         // decoder input, P layout
     DevBuf decR[SE_MAX_LEVELS];   // [B][Co8][T*2Fi][8] parity-planar
     DevBuf decP[SE_MAX_LEVELS];   // blended decoder level outputs, P layout
@@ -106,7 +115,7 @@ int plan_conv_p(se_engine *e, ConvPPlan &pl, int Ci, int Co, int FP, int Fi, int
     a.s = s; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.ntap = ntap;
     for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
     a.nchunk = nchunk; a.St = St; a.act = act; a.relu_lo = relu_lo; a.relu_hi = relu_hi;
-    a.out_mode = out_mode; a.row_perm = out_mode == kPOutP || out_mode == kPOutBlend;
+    a.out_mode = out_mode; a.row_perm = out_mode == kPOutP || out_mode == kPOutBlend || out_mode == kPOutGate;
     a.valid_m = FP; a.par_rows = 0; a.stats = nullptr;
     pl.CO = CO; pl.npair = npair; pl.terms = PL == 3 ? 6 : (PL == 2 ? 3 : 1);
     // weights [chunk][pair][plane][mtile][row 32][k 16]: k = half*8 + c <-> entry 2*pair + half = (tap, octet) tap-major
@@ -188,25 +197,31 @@ uint4 *decin_p(se_engine *e, int slot) { return reinterpret_cast<uint4 *>(e->cp-
 
 void select_all_p(se_engine *e) {
     for (int i = 0; i < e->L; i++)
-        for (ConvPPlan *p : {&e->cp->pv[i].enc, &e->cp->pv[i].dec_even, &e->cp->pv[i].dec_odd, &e->cp->pv[i].skip, &e->cp->pv[i].skipm})
+        for (ConvPPlan *p : {&e->cp->pv[i].enc, &e->cp->pv[i].dec_even, &e->cp->pv[i].dec_odd, &e->cp->pv[i].skip, &e->cp->pv[i].skipm, &e->cp->pv[i].gate[0], &e->cp->pv[i].gate[1]})
             select_convp_geometry(e, *p);
+    if (e->cp->pre_p)
+        for (int i = 0; i < e->npre; i++) select_convp_geometry(e, e->cp->pre[i]);
 }
 
 void free_state_p(se_engine *e) {
     if (!e->cp) return;
     se_convp_state &S = *e->cp;
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
-        for (ConvPPlan *p : {&S.pv[i].enc, &S.pv[i].dec_even, &S.pv[i].dec_odd, &S.pv[i].skip, &S.pv[i].skipm}) { dev_free(p->wx); dev_free(p->bias); }
+        for (ConvPPlan *p : {&S.pv[i].enc, &S.pv[i].dec_even, &S.pv[i].dec_odd, &S.pv[i].skip, &S.pv[i].skipm, &S.pv[i].gate[0], &S.pv[i].gate[1]}) { dev_free(p->wx); dev_free(p->bias); }
         dev_free(S.pv[i].sk.wx); dev_free(S.pv[i].sk.cst);
-        dev_free(S.xinP[i]); dev_free(S.encR[i]); dev_free(S.decR[i]); dev_free(S.decP[i]);
+        dev_free(S.xinP[i]); dev_free(S.encR[i]); dev_free(S.encA[i]); dev_free(S.decR[i]); dev_free(S.decP[i]);
     }
     for (int r = 0; r < kRing; r++) dev_free(S.decinP[r]);
+    for (int i = 0; i < 3; i++) { dev_free(S.pre[i].wx); dev_free(S.pre[i].bias); dev_free(S.pinP[i]); dev_free(S.pre_gw[i]); }
+    dev_free(S.preR);
     delete e->cp;
     e->cp = nullptr;
 }
 
 bool convp_supported(const se_engine *e) {
-    if (e->variant != 0) return false;  // CRN_ELU / student keep the first-generation path (pre-conv chain, pair-gated 1x1 convs)
+    // (CRN_ELU / student: the three 5-channel pre-conv blocks stay on their fp32 vector-ALU kernel and hand over to the plane
+    //  path with one conversion; the gated 1x1 pair of every encoder block is a k_conv_p epilogue, kPOutGate)
+    if (e->variant && e->Ch[0] > 8) return false;
     for (int i = 0; i <= e->L; i++)
         if (e->Ch[i] > 128) return false;
     return true;
@@ -215,6 +230,39 @@ bool convp_supported(const se_engine *e) {
 int prepare_weights_p(se_engine *e) {
     se_convp_state &S = *e->cp;
     const int L = e->L, T = e->T;
+    // The pre-conv blocks run on k_conv_p only with fp16 operands: a workgroup stages a 6-7 row x (F + 4 fd) column patch for
+    // 1-2 output rows, and with three bf16 planes that staging costs more than the scalar-weight vector-ALU kernel takes
+    // (measured, student B = 1024: 760 vs 450 us per block in f32, equal in bf16x3, 0.6x in fp16).  SE_PRE_P=0/1 overrides.
+    S.pre_p = e->npre > 0 && (getenv("SE_PRE_P") ? atoi(getenv("SE_PRE_P")) != 0 : operand_planes(e->precision) == 1);
+    for (int i = 0; i < e->npre && S.pre_p; i++) {  // Conv2d(5x5, dilation (fd,1), padding (2fd,4)) + ELU + gated pair (CRN_ELU.py:335-340)
+        const int C0 = e->Ch[0], F0 = e->F[0], fd = 1 << i;
+        const std::string p = "preconvlist." + std::to_string(i) + ".";
+        auto *w = param(e, p + "conv.weight", (size_t)C0 * C0 * 25);
+        auto *b = param(e, p + "conv.bias", C0);
+        auto *tw = param(e, p + "conv_trans.weight", (size_t)C0 * C0);
+        auto *tb = param(e, p + "conv_trans.bias", C0);
+        auto *gw = param(e, p + "conv_gated.weight", (size_t)C0 * C0);
+        auto *gb = param(e, p + "conv_gated.bias", C0);
+        if (!w || !b || !tw || !tb || !gw || !gb) return SE_ERR_PARAM_MISSING;
+        std::vector<std::array<int, 4>> taps;
+        for (int kf = 0; kf < 5; kf++)
+            for (int kt = 0; kt < 5; kt++) taps.push_back({kf, kt, kt, kf * fd});
+        const float *wp = w->data();
+        int rc = plan_conv_p(e, S.pre[i], C0, C0, F0, F0, 1, 2 * fd, -4, 5, 1, F0 + 4 * fd, taps,
+                             [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * C0 + ci) * 5 + kf) * 5 + kt]; }, *b, 0, C0, 2, kPOutPre);
+        if (rc) { S.pre_p = false; e->err.clear(); break; }  // (no tiling fits: the blocks stay on the fp32 vector-ALU kernel)
+        S.pre[i].name = "pre" + std::to_string(i);
+        ConvPArgs &a = S.pre[i].a;
+        a.Cy = C0; a.oT = F0; a.oo = 0; a.y_npos = T * F0; a.y_stream = (long)T * F0 * 8;
+        std::vector<float> g;
+        g.insert(g.end(), tw->begin(), tw->end());
+        g.insert(g.end(), gw->begin(), gw->end());
+        g.insert(g.end(), tb->begin(), tb->end());
+        g.insert(g.end(), gb->begin(), gb->end());
+        if ((rc = dev_upload(e, S.pre_gw[i], g))) return rc;
+        a.gatew = S.pre_gw[i].p;
+        S.pre[i].flops = 2.0 * C0 * C0 * 25 * F0 * T + 2.0 * 2 * C0 * C0 * F0 * T;
+    }
     for (int i = 0; i < L; i++) {
         const int Ci = e->Ch[i], Co = e->Ch[i + 1], Fi = e->F[i], Fo = e->F[i + 1], d = 1 << i;
         const std::string p = "convlist." + std::to_string(i) + ".";
@@ -226,12 +274,37 @@ int prepare_weights_p(se_engine *e) {
             for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, kt, kf});
         const float *wp = w->data();
         int rc = plan_conv_p(e, S.pv[i].enc, Ci, Co, Fo, Fi, 2, 2, -2 * d, 3, d, Fi + 4, taps,
-                             [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; }, *b, 0, Co, e->act, kPOutR);
+                             [=](int ci, int co, int kf, int kt) { return wp[(((size_t)co * Ci + ci) * 5 + kf) * 3 + kt]; }, *b, 0, Co, e->act,
+                             e->variant ? kPOutP : kPOutR);
         if (rc) return rc;
         S.pv[i].enc.name = "enc" + std::to_string(i);
         ConvPArgs &a = S.pv[i].enc.a;
         a.oT = Fo; a.oo = 0; a.y_npos = T * Fo; a.y_stream = (long)((Co + 7) / 8) * T * Fo * 8;
         a.stats_lo = 0; a.stats_hi = Co;
+        S.pv[i].gate[0].active = S.pv[i].gate[1].active = false;
+        if (e->variant) {  // act(conv) -> P layout -> gated 1x1 pair (CRN_ELU.py:223-224, 240) -> R layout + statistics
+            a.Cy = Co; a.Fy = Fo; a.yp_stream = (long)((Co + 7) / 8) * operand_planes(e->precision) * T * Fo;
+            auto *tw = param(e, p + "conv_trans.weight", (size_t)Co * Co);
+            auto *tb = param(e, p + "conv_trans.bias", Co);
+            auto *gw = param(e, p + "conv_gated.weight", (size_t)Co * Co);
+            auto *gb = param(e, p + "conv_gated.bias", Co);
+            if (!tw || !tb || !gw || !gb) return SE_ERR_PARAM_MISSING;
+            const float *twp = tw->data(), *gwp = gw->data();
+            const int nparts = Co > 64 ? 2 : 1, cpart = ((Co + nparts - 1) / nparts + 7) / 8 * 8;
+            std::vector<std::array<int, 4>> t1 = {{0, 0, 0, 0}};
+            for (int part = 0; part < nparts; part++) {
+                const int c0 = part * cpart, cn = std::min(cpart, Co - c0);
+                std::vector<float> bias2(2 * cn);
+                for (int c = 0; c < cn; c++) { bias2[2 * c] = (*tb)[c0 + c]; bias2[2 * c + 1] = (*gb)[c0 + c]; }
+                ConvPPlan &g = S.pv[i].gate[part];
+                if ((rc = plan_conv_p(e, g, Co, 2 * cn, Fo, Fo, 1, 0, 0, 1, 0, Fo, t1,
+                                      [=](int ci, int row, int, int) { const int c = c0 + row / 2; return (row & 1) ? gwp[(size_t)c * Co + ci] : twp[(size_t)c * Co + ci]; },
+                                      bias2, 0, 0, 0, kPOutGate))) return rc;
+                g.name = "gate" + std::to_string(i);
+                g.a.Cy = cn; g.a.gate_c0 = c0; g.a.oT = Fo; g.a.oo = 0; g.a.y_npos = T * Fo; g.a.y_stream = a.y_stream;
+                g.flops = 2.0 * 2 * cn * Co * Fo * T;
+            }
+        }
         S.pv[i].enc.flops = 2.0 * Co * Ci * 15 * Fo * T;
     }
     for (int j = 0; j < L; j++) {
@@ -369,9 +442,19 @@ int alloc_state_p(se_engine *e, hipStream_t st) {
         if ((rc = dev_alloc(e, S.encR[i], (size_t)B * ((Co + 7) / 8) * T * Fo * 8))) return rc;
         // channel slots beyond Co of the last octet are never written; consumers scale them by zero, so they must be finite
         HIPCHECK(e, hipMemsetAsync(S.encR[i].p, 0, (size_t)B * ((Co + 7) / 8) * T * Fo * 8 * sizeof(float), st));
+        if (e->variant && (rc = dev_alloc(e, S.encA[i], (size_t)B * ((Co + 7) / 8) * PL * T * Fo * 4))) return rc;
     }
     for (int r = 0; r < kRing; r++)
         if ((rc = dev_alloc(e, S.decinP[r], (size_t)B * ((e->Ch[L] + 7) / 8) * PL * T * e->F[L] * 4))) return rc;
+    if (S.pre_p) {
+        S.pslot_elems = (long)PL * T * e->F[0] * B;
+        for (int i = 0; i < e->npre; i++) {
+            if ((rc = dev_alloc(e, S.pinP[i], (size_t)S.pslot_elems * kRing * 4))) return rc;
+            HIPCHECK(e, hipMemsetAsync(S.pinP[i].p, 0, (size_t)S.pslot_elems * kRing * 16, st));  // every slot: zero history wherever the ring starts
+            if ((rc = dev_alloc(e, e->pre_stats[i], (size_t)B * 2 * (S.pre[i].grid_x + 1)))) return rc;
+        }
+        if ((rc = dev_alloc(e, S.preR, (size_t)B * T * e->F[0] * 8))) return rc;
+    }
     for (int j = 0; j < L; j++) {
         const int lvl = L - 1 - j, Co = lvl == 0 ? 2 : e->Ch[lvl], Fi = e->F[lvl + 1];
         const size_t nR = lvl == 0 ? (size_t)B * T * Fi * 8 : (size_t)B * ((Co + 7) / 8) * T * 2 * Fi * 8;
@@ -382,7 +465,7 @@ int alloc_state_p(se_engine *e, hipStream_t st) {
     // statistics slabs are shared with the first-generation path; make sure they hold the new grids
     for (int i = 0; i < L; i++) {
         PLevel &pv = S.pv[i];
-        if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * (pv.enc.grid_x + 1)))) return rc;
+        if ((rc = dev_alloc(e, e->enc_stats[i], (size_t)B * 2 * (pv.enc.grid_x + (pv.gate[0].active ? pv.gate[0].grid_x : 0) + (pv.gate[1].active ? pv.gate[1].grid_x : 0) + 1)))) return rc;
         if ((rc = dev_alloc(e, e->dec_stats[i], (size_t)B * 2 * (pv.dec_even.grid_x + (pv.dec_odd.active ? pv.dec_odd.grid_x : 0) + 1)))) return rc;
         if ((rc = dev_alloc(e, e->skip_stats[i], (size_t)B * 2 * ((pv.skipm.active ? pv.skipm.grid_x : 0) + 1)))) return rc;
     }
@@ -394,7 +477,45 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
     se_convp_state &S = *e->cp;
     const int L = e->L, T = e->T, B = e->B, PL = operand_planes(e->precision);
     int rc;
-    {
+    if (e->variant && S.pre_p) {  // features and the three pre-conv blocks x = m(x) + x on the plane path
+        const int TF = T * e->F[0], C0 = e->Ch[0];
+        {
+            ProfScope ps(e, "k_featurize_p", "featurize", 0, st);
+            FeatPArgs f{spec, sB, sM, sT, sF, reinterpret_cast<uint4 *>(S.pinP[0].p) + (long)cur * S.pslot_elems, (long)PL * TF, e->M, T, e->F[0], e->atan2_phase};
+            launch_k_featurize_p(PL, dim3((TF + 255) / 256, B), st, f);
+            HIPCHECK(e, hipGetLastError());
+        }
+        for (int i = 0; i < e->npre; i++) {
+            ConvPPlan &pl = S.pre[i];
+            ConvPArgs a = pl.a;
+            a.xbase = reinterpret_cast<const uint4 *>(S.pinP[i].p);
+            a.xbytes = (unsigned)((size_t)S.pslot_elems * kRing * 16);
+            a.cur_off = (long)cur * S.pslot_elems;
+            a.prev_off = (long)prev * S.pslot_elems;
+            a.y = S.preR.p;
+            a.stats = e->pre_stats[i].p; a.stats_nslot = pl.grid_x; a.stats_slot0 = 0;
+            if ((rc = launch_conv_p(e, pl, a, st, ("pre" + std::to_string(i)).c_str()))) return rc;
+            ProfScope ps(e, "k_gln_p", "gln", 0, st);
+            GlnPArgs g{};
+            g.x = S.preR.p; g.x_stream = a.y_stream; g.C = C0; g.C8 = 1; g.T = T; g.F = e->F[0]; g.in_oT = e->F[0];
+            g.w = e->lv[i].pre_nw.p; g.b = e->lv[i].pre_nb.p;
+            g.st = SlabStats{e->pre_stats[i].p, pl.grid_x, (long)C0 * TF, e->eps_mode};
+            g.res = reinterpret_cast<const uint4 *>(S.pinP[i].p) + (long)cur * S.pslot_elems; g.res_stream = (long)PL * TF;
+            g.mode = 0;
+            g.y = i + 1 < e->npre ? reinterpret_cast<uint4 *>(S.pinP[i + 1].p) + (long)cur * S.pslot_elems
+                                  : reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0];
+            g.y_stream = (long)PL * TF;
+            launch_k_gln_p(PL, dim3((TF + 1023) / 1024, 1, B), st, g);
+            HIPCHECK(e, hipGetLastError());
+        }
+    } else if (e->variant) {  // the same blocks on their fp32 vector-ALU kernel (first generation), then one conversion into the P layout
+        if ((rc = stage_features_pre(e, cur, spec, sB, sM, sT, sF, st))) return rc;
+        ProfScope ps(e, "k_f32_to_p", "feat_to_p", 0, st);
+        const int TF = T * e->F[0];
+        F32ToPArgs f{e->xin[0][cur].p, reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0], (long)PL * TF, e->Ch[0], TF};
+        launch_k_f32_to_p(PL, dim3((TF + 255) / 256, B), st, f);
+        HIPCHECK(e, hipGetLastError());
+    } else {
         ProfScope ps(e, "k_featurize_p", "featurize", 0, st);
         const int TF = T * e->F[0];
         FeatPArgs f{spec, sB, sM, sT, sF, reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0], (long)PL * TF, e->M, T, e->F[0], e->atan2_phase};
@@ -409,14 +530,33 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
         a.xbytes = (unsigned)((size_t)S.slot_elems[i] * kRing * 16);
         a.cur_off = (long)cur * S.slot_elems[i];
         a.prev_off = (long)prev * S.slot_elems[i];
-        a.y = S.encR[i].p;
-        a.stats = e->enc_stats[i].p; a.stats_nslot = pl.grid_x; a.stats_slot0 = 0;
-        if ((rc = launch_conv_p(e, pl, a, st, ("enc" + std::to_string(i)).c_str()))) return rc;
+        int nslot = pl.grid_x;
+        if (!e->variant) {
+            a.y = S.encR[i].p;
+            a.stats = e->enc_stats[i].p; a.stats_nslot = pl.grid_x; a.stats_slot0 = 0;
+            if ((rc = launch_conv_p(e, pl, a, st, ("enc" + std::to_string(i)).c_str()))) return rc;
+        } else {
+            a.yp = reinterpret_cast<uint4 *>(S.encA[i].p);
+            if ((rc = launch_conv_p(e, pl, a, st, ("enc" + std::to_string(i)).c_str()))) return rc;
+            const int n0 = S.pv[i].gate[0].grid_x, n1 = S.pv[i].gate[1].active ? S.pv[i].gate[1].grid_x : 0;
+            nslot = n0 + n1;
+            for (int part = 0; part < 2; part++) {
+                ConvPPlan &gp = S.pv[i].gate[part];
+                if (!gp.active) continue;
+                ConvPArgs g = gp.a;
+                g.xbase = reinterpret_cast<const uint4 *>(S.encA[i].p);
+                g.xbytes = (unsigned)((size_t)B * ((Co + 7) / 8) * PL * T * Fo * 16);
+                g.cur_off = 0; g.prev_off = -1;
+                g.y = S.encR[i].p;
+                g.stats = e->enc_stats[i].p; g.stats_nslot = nslot; g.stats_slot0 = part ? n0 : 0;
+                if ((rc = launch_conv_p(e, gp, g, st, ("gate" + std::to_string(i)).c_str()))) return rc;
+            }
+        }
         ProfScope ps(e, "k_gln_p", "gln", 0, st);
         GlnPArgs g{};
         g.x = S.encR[i].p; g.x_stream = a.y_stream; g.C = Co; g.C8 = (Co + 7) / 8; g.T = T; g.F = Fo; g.in_oT = Fo;
         g.w = e->lv[i].enc_nw.p; g.b = e->lv[i].enc_nb.p;
-        g.st = SlabStats{e->enc_stats[i].p, pl.grid_x, (long)Co * T * Fo, e->eps_mode};
+        g.st = SlabStats{e->enc_stats[i].p, nslot, (long)Co * T * Fo, e->eps_mode};
         if (i + 1 < L) {
             g.mode = 0;
             g.y = reinterpret_cast<uint4 *>(S.xinP[i + 1].p) + (long)cur * S.slot_elems[i + 1];

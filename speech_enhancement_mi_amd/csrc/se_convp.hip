@@ -8,7 +8,7 @@
 #include "conv_p.hip.h"
 
 #if !defined(SE_CP_PL) || !defined(SE_CP_NTAP)
-#error "compile with -DSE_CP_PL=1|2|3 -DSE_CP_NTAP=15|9|6|1"
+#error "compile with -DSE_CP_PL=1|2|3 -DSE_CP_NTAP=25|15|9|6|1"
 #endif
 #define SE_CAT4_(a, b, c, d) a##b##c##d
 #define SE_CAT4(a, b, c, d) SE_CAT4_(a, b, c, d)
@@ -20,6 +20,8 @@ namespace se {
 #define SE_CP_NTS(X, CO_) X(1, CO_) X(2, CO_) X(3, CO_) X(4, CO_) X(6, CO_) X(8, CO_) X(10, CO_) X(12, CO_)
 #if SE_CP_NTAP == 1
 #define SE_CP_ALL(X) SE_CP_NTS(X, 1) SE_CP_NTS(X, 2) SE_CP_NTS(X, 4)
+#elif SE_CP_NTAP == 25  // 5x5 pre-conv blocks of CRN_ELU: one channel octet, patches of <= 4 tiles per wave fit the LDS-DMA budget
+#define SE_CP_ALL(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1)
 #else
 #define SE_CP_ALL(X) SE_CP_NTS(X, 1)
 #endif
@@ -46,6 +48,11 @@ void launch_k_featurize_p(int PL, dim3 grid, hipStream_t st, const FeatPArgs &a)
     if (PL == 1) hipLaunchKernelGGL(k_featurize_p<1>, grid, dim3(256), 0, st, a);
     else if (PL == 2) hipLaunchKernelGGL(k_featurize_p<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_featurize_p<3>, grid, dim3(256), 0, st, a);
+}
+void launch_k_f32_to_p(int PL, dim3 grid, hipStream_t st, const F32ToPArgs &a) {
+    if (PL == 1) hipLaunchKernelGGL(k_f32_to_p<1>, grid, dim3(256), 0, st, a);
+    else if (PL == 2) hipLaunchKernelGGL(k_f32_to_p<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_f32_to_p<3>, grid, dim3(256), 0, st, a);
 }
 void launch_k_gln_p(int PL, dim3 grid, hipStream_t st, const GlnPArgs &a) {
     if (PL == 1) hipLaunchKernelGGL(k_gln_p<1>, grid, dim3(256), 0, st, a);

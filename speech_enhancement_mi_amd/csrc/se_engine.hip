@@ -774,12 +774,13 @@ int launch_gln_ew(se_engine *e, const float *x, float *y, const float *w, const 
 // TemporalCRN.forward on device in three stages; each reads/writes the ring slot `cur` (history from slot `prev`).
 // spec: (b, m, t, f) strides; out: (b, t, f) strides (cf2 units).
 // Stage 1: features + (CRN_ELU pre-convs) + encoder  ->  xin[*][cur], gru_in[cur]
-int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
-    const int L = e->L, T = e->T, B = e->B;
+// features (CRN.py:463-467) and, for CRN_ELU / the student, the three frequency-dilated pre-conv blocks -> xin[0][cur] (fp32)
+int stage_features_pre(se_engine *e, int cur, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
+    const int T = e->T, B = e->B;
     int rc;
     e->parity ^= 1;
     const int pcur = e->parity, pprev = pcur ^ 1;
-    {  // features (CRN.py:463-467)
+    {
         ProfScope ps(e, "k_featurize", "featurize", 0, st);
         float *dst = e->npre ? e->pin[0][pcur].p : e->xin[0][cur].p;
         FeatArgs f{spec, sB, sM, sT, sF, dst, e->M, T, e->F[0], e->atan2_phase};
@@ -797,6 +798,13 @@ int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, lon
         if ((rc = launch_gln_ew(e, e->pre_g.p, dst, e->lv[i].pre_nw.p, e->lv[i].pre_nb.p, e->pre_stats[i].p, ns, n, 0, C0, T, F0, st,
                                 e->pin[i][pcur].p))) return rc;
     }
+    return 0;
+}
+
+int stage_encoder(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
+    const int L = e->L, T = e->T;
+    int rc;
+    if ((rc = stage_features_pre(e, cur, spec, sB, sM, sT, sF, st))) return rc;
     for (int i = 0; i < L; i++) {  // encoder (CRN.py:471-474; CRN_ELU.py:233-247)
         const int Co = e->Ch[i + 1], Fo = e->F[i + 1];
         const long n = (long)Co * T * Fo;
@@ -1363,6 +1371,11 @@ int se_reset_stream(se_engine *e, int stream_index, void *stream) {
         HIPCHECK(e, hipMemsetAsync(e->xin[i][e->slot].p + per * b, 0, per * sizeof(float), st));
     }
     for (int i = 0; i < e->npre; i++) {
+        if (e->use_p && e->cp->pre_p) {
+            const size_t per16 = (size_t)(e->cp->pslot_elems / e->B);
+            HIPCHECK(e, hipMemsetAsync(e->cp->pinP[i].p + ((size_t)e->slot * e->cp->pslot_elems + per16 * b) * 4, 0, per16 * 16, st));
+            continue;
+        }
         const size_t per = (size_t)e->Ch[0] * T * e->F[0];
         HIPCHECK(e, hipMemsetAsync(e->pin[i][e->parity].p + per * b, 0, per * sizeof(float), st));
     }
@@ -1762,6 +1775,15 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
         int rc = ensure_ready(e);
         if (rc) return rc;
         DevBuf tmp;
+        // On the plane path the operands of the re-run live in the P layout: they are summed back to fp32 on the host and put
+        // into the first-generation buffers the re-run reads (a tap is a training / debugging aid, not part of the hot path).
+        auto p_to_f32 = [&](const float *psrc, int C_, int F_, float *dst) -> int {
+            std::vector<float> h((size_t)B * C_ * T * F_);
+            int r = p_to_host(e, psrc, C_, F_, h.data(), st, false);
+            if (r) return r;
+            HIPCHECK(e, hipMemcpy(dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            return 0;
+        };
         auto finish = [&](int C_, int F_, bool raw_flat) -> int {
             const size_t n_ = (size_t)B * C_ * T * F_;
             if (count) *count = (int64_t)n_;
@@ -1779,6 +1801,11 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
         };
         if (idx == 0) {
             const int i = L - 1, Co = e->Ch[L], Fo = e->F[L];
+            if (e->use_p) {
+                se_convp_state &S = *e->cp;
+                if ((rc = p_to_f32(S.xinP[i].p + (size_t)cur * S.slot_elems[i] * 4, e->Ch[i], e->F[i], e->xin[i][cur].p)) ||
+                    (rc = p_to_f32(S.xinP[i].p + (size_t)prev * S.slot_elems[i] * 4, e->Ch[i], e->F[i], e->xin[i][prev].p))) return rc;
+            }
             if ((rc = dev_alloc(e, tmp, (size_t)B * Co * T * Fo))) return rc;
             ConvPlan pl = e->lv[i].enc;
             pl.a.relu_lo = pl.a.relu_hi = 0;
@@ -1796,6 +1823,11 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
         const int Co = e->Ch[lvl], Fo = 2 * e->F[lvl + 1] - 1;
         if ((rc = dev_alloc(e, tmp, (size_t)B * Co * T * Fo))) return rc;
         const float *xin = j == 0 ? e->dec_in[cur].p : e->dec_out[j - 1].p;
+        if (e->use_p) {
+            se_convp_state &S = *e->cp;
+            const int Cin = e->Ch[lvl + 1], Fin = e->F[lvl + 1];
+            if ((rc = p_to_f32(j == 0 ? S.decinP[cur].p : S.decP[j - 1].p, Cin, Fin, const_cast<float *>(xin)))) { dev_free(tmp); return rc; }
+        }
         ConvPlan pe = e->lv[j].dec_even, po = e->lv[j].dec_odd;
         pe.a.relu_lo = pe.a.relu_hi = 0;
         po.a.relu_lo = po.a.relu_hi = 0;
@@ -1844,6 +1876,9 @@ int se_export_state(se_engine *e, const char *name, float *host_out, int64_t cap
         if (e->use_p && !is_pbuf) {
             int rc = p_to_host(e, e->cp->xinP[idx].p + (size_t)e->slot * e->cp->slot_elems[idx] * 4, C, F, h.data(), st, false);
             if (rc) return rc;
+        } else if (e->use_p && e->cp->pre_p) {
+            int rc = p_to_host(e, e->cp->pinP[idx].p + (size_t)e->slot * e->cp->pslot_elems * 4, C, F, h.data(), st, false);
+            if (rc) return rc;
         } else
         HIPCHECK(e, hipMemcpy(h.data(), (is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, nsrc * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t bc = 0; bc < (size_t)B * C; bc++)
@@ -1877,6 +1912,7 @@ int se_import_state(se_engine *e, const char *name, const float *host_in, int64_
             for (int f = 0; f < F; f++)
                 for (int p = 0; p < P; p++) h[(bc * T + (T - P + p)) * F + f] = host_in[(bc * F + f) * P + p];
         if (e->use_p && !is_pbuf) return host_to_p(e, h, C, F, e->cp->xinP[idx].p + (size_t)e->slot * e->cp->slot_elems[idx] * 4);
+        if (e->use_p && e->cp->pre_p) return host_to_p(e, h, C, F, e->cp->pinP[idx].p + (size_t)e->slot * e->cp->pslot_elems * 4);
         HIPCHECK(e, hipMemcpy((is_pbuf ? e->pin[idx][e->parity] : e->xin[idx][e->slot]).p, h.data(), nsrc * sizeof(float), hipMemcpyHostToDevice));
         return SE_OK;
     }

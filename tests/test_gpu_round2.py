@@ -363,3 +363,27 @@ def test_plane_gemm_matches_first_generation_gemm(monkeypatch):
         taps[flag] = np.asarray(e.read_tap(last))
     assert rel_rms(outs["1"], outs["0"]) < 2e-6
     assert taps["1"].shape == taps["0"].shape and rel_rms(taps["1"], taps["0"]) < 1e-6
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_preconv_blocks_on_plane_path_match_vector_kernel(monkeypatch, variant):
+    """CRN_ELU / student: the three 5x5 pre-conv blocks on k_conv_p<25,...> (default only with fp16 operands, SE_PRE_P=1 forces
+    it) against the fp32 vector-ALU kernel, fp32-accurate mode: outputs, the pre-chain output tap and the exported
+    4-frame pre-conv buffers agree to fp32 round-off (CRN_ELU.py:335-340, 375-376)."""
+    from test_gpu_parity import FULL400, STUDENT400, _engine_v, _cuda, rel_rms
+    cfg = FULL400 if variant == 1 else STUDENT400
+    mix, _ = synth.synth_utterances(3, 9600, 3, seed=91)
+    x = _cuda(mix)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SE_PRE_P", flag)
+        e = _engine_v(cfg, variant, seed=4)
+        y = e.realtime_process(x).cpu().numpy()
+        e.reset(3)
+        for k in range(2):
+            e.step(x[:, :, 3200 * k:3200 * (k + 1)].contiguous())
+        res[flag] = (y, np.asarray(e.read_tap("feat")), [np.asarray(e.export_state(f"pbuf{i}")) for i in range(3)])
+    assert rel_rms(res["1"][0], res["0"][0]) < 2e-6
+    assert rel_rms(res["1"][1], res["0"][1]) < 1e-6
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert a.shape == b.shape and rel_rms(a, b) < 1e-6
