@@ -196,6 +196,22 @@ int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const 
 int se_train_gru_bwd_gates(const float *d1, int64_t d1_ld, const float *d2, const float *d3, const float *gates, int64_t gates_ld, const float *hprev,
                            int64_t hprev_ld, float *dgi, float *dgh, int64_t dg_ld, float *dhz, int B, int H, void *stream);
 
+/* ---- 8f-4: synthetic multi-microphone training data on the GPU (csrc/se_synth.hip) -------------------------------------
+ * Replaces the reference's CPU/gpuRIR input pipeline for DP training: multichannel.py:37-103 (Single2Multi.simulate: shoebox
+ * image-source RIRs, dry source * RIR), augment.py:29-77 (AddNoise.forward), data_c.py:236-250 (dynamic_mix, MAX_AMP guard).
+ * All pointers are DEVICE pointers, all calls enqueue on `stream`; 0 or a negative se_status, se_synth_last_error() = message.
+ *   se_synth_rir   rir[R][S][M][Lr]: image-source model of R rooms (room[R][3] sizes in m, beta[R][6] wall reflection
+ *                  coefficients x0,x1,y0,y1,z0,z1, src[R][S][3], mic[R][M][3]); images -n/2 .. n/2-1 per axis (nx, ny, nz);
+ *                  fractional delays by a Hann-windowed sinc of 8 ms; Lr <= 36864
+ *   se_synth_fir   y[R][S][M][L] = x[R][S][L] * rir, truncated to L samples (gpuRIR.simulateTrajectory of a static source)
+ *   se_synth_mix   the last source is the noise: mix[R][M][L], noise[R][M][L], absmax[R][M] (scratch) */
+const char *se_synth_last_error(void);
+int se_synth_rir(const float *room, const float *beta, const float *src, const float *mic, int R, int S, int M, int nx, int ny, int nz,
+                 float fs, float c, int Lr, float *rir, void *stream);
+int se_synth_fir(const float *x, const float *rir, int R, int S, int M, int64_t L, int Lr, float *y, void *stream);
+int se_synth_mix(const float *y, const float *snr_db, int R, int S, int M, int64_t L, float max_amp, float *mix, float *noise, float *absmax,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

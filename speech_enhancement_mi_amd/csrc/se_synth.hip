@@ -1,0 +1,223 @@
+// se_synth.hip - synthetic multi-microphone training data on the GPU: the part of the reference's input
+// pipeline that kept it single-GPU (README.md:24).  Replaces
+//   multichannel.py:37-103   Single2Multi.simulate: shoebox room, image-source room impulse responses for every
+//                            (source, microphone) pair, dry source * RIR
+//   augment.py:29-77         AddNoise.forward: SNR-controlled mixing with per-channel amplitudes, clip guard
+//   data_c.py:236-250        dynamic_mix: sum of the reverberant sources + noise, MAX_AMP peak normalisation
+// The reference calls gpuRIR (un-vendored, unpinned, not in this image) for the RIRs; what is restated here is the published
+// image-source model it implements (Allen & Berkley 1979; Diaz-Guerra et al., "gpuRIR", 2021, section 2): every image of the
+// source contributes amplitude prod(beta_wall ^ reflections) / (4 pi d) at the fractional delay d fs / c through a
+// Hann-windowed sinc of Tw = 8 ms.  gpuRIR's diffuse-tail model after Tdiff is NOT restated (parity unpinned: no fixture of
+// the reference holds an RIR); the image expansion runs to the image counts the caller passes.  The numpy restatement
+// speech_enhancement_mi_amd/synth.py (image_rir / fir_filter / mix_noise) is the checker (tests/test_synth_gen.py).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <string>
+
+#include "../../include/se_engine.h"
+
+namespace {
+
+thread_local std::string g_synth_error;
+int synth_fail(const char *msg) { g_synth_error = msg; return SE_ERR_ARG; }
+
+constexpr float kPi = 3.14159265358979323846f;
+
+struct RirArgs {
+    const float *room;  // [R][3]
+    const float *beta;  // [R][6] reflection coefficients x0, x1, y0, y1, z0, z1
+    const float *src;   // [R][S][3]
+    const float *mic;   // [R][M][3]
+    float *rir;         // [R][S][M][Lr]
+    int S, M, Lr, nx, ny, nz;
+    float fs, c;
+    int Tw;             // window length in samples (even)
+};
+
+__device__ __forceinline__ void image_axis(int n, float L, float xs, float b0, float b1, float &pos, float &amp) {
+    // image n of a source at xs in [0, L]: even n -> n L + xs, odd n -> (n + 1) L - xs; |n| wall reflections, split between
+    // the wall at 0 (b0) and the wall at L (b1)
+    const int an = n < 0 ? -n : n;
+    int r0, r1;
+    if ((an & 1) == 0) { pos = n * L + xs; r0 = r1 = an >> 1; }
+    else {
+        pos = (n + 1) * L - xs;
+        if (n > 0) { r1 = (an + 1) >> 1; r0 = (an - 1) >> 1; }
+        else { r0 = (an + 1) >> 1; r1 = (an - 1) >> 1; }
+    }
+    amp = powf(b0, (float)r0) * powf(b1, (float)r1);
+}
+
+// one workgroup per (room, source, microphone): the RIR is accumulated in LDS with ds_add_f32, one image per thread at a time
+__global__ __launch_bounds__(1024) void k_rir_ism(RirArgs a) {
+    extern __shared__ float h[];
+    const int m = blockIdx.x, s = blockIdx.y, r = blockIdx.z, tid = threadIdx.x;
+    for (int i = tid; i < a.Lr; i += 1024) h[i] = 0.0f;
+    __syncthreads();
+    const float *room = a.room + r * 3, *beta = a.beta + r * 6;
+    const float *sp = a.src + ((long)r * a.S + s) * 3, *mp = a.mic + ((long)r * a.M + m) * 3;
+    const long nimg = (long)a.nx * a.ny * a.nz;
+    const float half = 0.5f * (float)a.Tw;
+    for (long i = tid; i < nimg; i += 1024) {
+        const int iz = (int)(i % a.nz), iy = (int)((i / a.nz) % a.ny), ix = (int)(i / ((long)a.nz * a.ny));
+        float px, py, pz, ax, ay, az;
+        image_axis(ix - a.nx / 2, room[0], sp[0], beta[0], beta[1], px, ax);
+        image_axis(iy - a.ny / 2, room[1], sp[1], beta[2], beta[3], py, ay);
+        image_axis(iz - a.nz / 2, room[2], sp[2], beta[4], beta[5], pz, az);
+        const float dx = px - mp[0], dy = py - mp[1], dz = pz - mp[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float amp = ax * ay * az / (4.0f * kPi * fmaxf(d, 1e-3f));
+        const float tau = d * a.fs / a.c;
+        const int k0 = (int)ceilf(tau - half), k1 = (int)floorf(tau + half);
+        for (int k = max(k0, 0); k <= min(k1, a.Lr - 1); k++) {
+            const float x = (float)k - tau;
+            const float w = 0.5f * (1.0f + cosf(2.0f * kPi * x / (float)a.Tw));
+            const float sc = fabsf(x) < 1e-6f ? 1.0f : sinf(kPi * x) / (kPi * x);
+            __hip_atomic_fetch_add(&h[k], amp * w * sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    float *out = a.rir + (((long)r * a.S + s) * a.M + m) * a.Lr;
+    for (int i = tid; i < a.Lr; i += 1024) out[i] = h[i];
+}
+
+// y[r][s][m][n] = sum_k rir[r][s][m][k] x[r][s][n - k], n < L: direct FIR, 256 threads x 4 consecutive outputs per workgroup,
+// taps walked in chunks of 256 through LDS (x window of 1024 + 255 samples, reversed tap order)
+__global__ __launch_bounds__(256) void k_fir(const float *x, const float *rir, float *y, int S, int M, int L, int Lr) {
+    __shared__ float xs[1024 + 256 + 4];
+    __shared__ float hs[256];
+    const int m = blockIdx.y % M, s = (blockIdx.y / M) % S, r = blockIdx.y / (M * S), tid = threadIdx.x;
+    const int n0 = blockIdx.x * 1024;
+    const float *xr = x + ((long)r * S + s) * L;
+    const float *hr = rir + (((long)r * S + s) * M + m) * Lr;
+    float acc[4] = {0, 0, 0, 0};
+    const int kmax = min(Lr, n0 + 1024);  // taps beyond the newest output index only see x[< 0] = 0
+    for (int k0 = 0; k0 < kmax; k0 += 256) {
+        __syncthreads();
+        hs[tid] = k0 + tid < Lr ? hr[k0 + tid] : 0.0f;
+        // window: x[n0 - k0 - 255 .. n0 - k0 + 1023] -> xs[0 .. 1278]
+        const int base = n0 - k0 - 255;
+        for (int i = tid; i < 1024 + 255; i += 256) {
+            const int j = base + i;
+            xs[i] = (j >= 0 && j < L) ? xr[j] : 0.0f;
+        }
+        __syncthreads();
+        // output n = n0 + 4 tid + q, tap k = k0 + kk: x index n - k -> xs[(n - k) - base] = xs[4 tid + q - kk + 255]
+        float w0 = xs[4 * tid + 255], w1 = xs[4 * tid + 256], w2 = xs[4 * tid + 257], w3 = xs[4 * tid + 258];
+#pragma unroll 8
+        for (int kk = 0; kk < 256; kk++) {
+            const float hk = hs[kk];
+            acc[0] += hk * w0; acc[1] += hk * w1; acc[2] += hk * w2; acc[3] += hk * w3;
+            w3 = w2; w2 = w1; w1 = w0;
+            w0 = xs[4 * tid + 254 - kk < 0 ? 0 : 4 * tid + 254 - kk];
+        }
+    }
+    float *yr = y + (((long)r * S + s) * M + m) * L;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (n0 + 4 * tid + q < L) yr[n0 + 4 * tid + q] = acc[q];
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// AddNoise.forward (augment.py:29-77) per (room, channel): clean = sum of the speech sources, noise = the last source.
+//   f = 1 / (10^(snr/20) + 1);  noisy = (1 - f) clean + noise * f * mean|clean| / (mean|noise| + 1e-8);  noisy /= max(1, max|noisy|)
+// absmax[r][m] receives max|noisy| after that division (for the MAX_AMP guard of data_c.py:249-250).
+__global__ __launch_bounds__(256) void k_mix(const float *y, const float *snr_db, float *mix, float *noise, float *absmax, int S, int M, int L) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    const float *yb = y + (long)r * S * M * L;
+    float ac = 0.0f, an = 0.0f;
+    for (int n = tid; n < L; n += 256) {
+        float c = 0.0f;
+        for (int s = 0; s + 1 < S; s++) c += yb[((long)s * M + m) * L + n];
+        ac += fabsf(c);
+        an += fabsf(yb[((long)(S - 1) * M + m) * L + n]);
+    }
+    ac = block_sum(ac, red) / (float)L;
+    an = block_sum(an, red) / (float)L;
+    const float f = 1.0f / (powf(10.0f, snr_db[r] / 20.0f) + 1.0f);
+    const float gn = f * ac / (an + 1e-8f);
+    float *mo = mix + ((long)r * M + m) * L, *no = noise + ((long)r * M + m) * L;
+    float mx = 0.0f;
+    for (int n = tid; n < L; n += 256) {
+        float c = 0.0f;
+        for (int s = 0; s + 1 < S; s++) c += yb[((long)s * M + m) * L + n];
+        const float nz = gn * yb[((long)(S - 1) * M + m) * L + n];
+        const float v = (1.0f - f) * c + nz;
+        mo[n] = v; no[n] = nz;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    mx = block_max(mx, red);
+    const float div = fmaxf(mx, 1.0f);
+    if (div > 1.0f)
+        for (int n = tid; n < L; n += 256) mo[n] /= div;
+    if (tid == 0) absmax[r * M + m] = mx / div;
+}
+
+// data_c.py:249-250: if max|mix| >= MAX_AMP: mix *= MAX_AMP / (max|mix| + 1e-10)   (max over all channels of the room)
+__global__ __launch_bounds__(256) void k_peak(float *mix, const float *absmax, int M, int L, float max_amp) {
+    const int r = blockIdx.y;
+    float mx = 0.0f;
+    for (int m = 0; m < M; m++) mx = fmaxf(mx, absmax[r * M + m]);
+    if (mx < max_amp) return;
+    const float g = max_amp / (mx + 1e-10f);
+    const long n = (long)M * L;
+    float *p = mix + (long)r * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *se_synth_last_error(void) { return g_synth_error.c_str(); }
+
+int se_synth_rir(const float *room, const float *beta, const float *src, const float *mic, int R, int S, int M, int nx, int ny, int nz,
+                 float fs, float c, int Lr, float *rir, void *stream) {
+    if (!room || !beta || !src || !mic || !rir) return synth_fail("null argument");
+    if (R <= 0 || S <= 0 || M <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || Lr <= 0) return synth_fail("sizes must be positive");
+    if (Lr > 36 * 1024) return synth_fail("RIR longer than 36864 samples does not fit the LDS accumulator");
+    int Tw = (int)lrintf(8e-3f * fs);
+    Tw += Tw & 1;
+    RirArgs a{room, beta, src, mic, rir, S, M, Lr, nx, ny, nz, fs, c, Tw};
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rir_ism), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * 4); attr = true; }
+    hipLaunchKernelGGL(k_rir_ism, dim3(M, S, R), dim3(1024), (size_t)Lr * sizeof(float), static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : synth_fail("k_rir_ism launch failed");
+}
+
+int se_synth_fir(const float *x, const float *rir, int R, int S, int M, int64_t L, int Lr, float *y, void *stream) {
+    if (!x || !rir || !y) return synth_fail("null argument");
+    if (R <= 0 || S <= 0 || M <= 0 || L <= 0 || Lr <= 0 || L > (1 << 30)) return synth_fail("sizes must be positive");
+    hipLaunchKernelGGL(k_fir, dim3((unsigned)((L + 1023) / 1024), R * S * M), dim3(256), 0, static_cast<hipStream_t>(stream), x, rir, y, S, M, (int)L, Lr);
+    return hipGetLastError() == hipSuccess ? SE_OK : synth_fail("k_fir launch failed");
+}
+
+int se_synth_mix(const float *y, const float *snr_db, int R, int S, int M, int64_t L, float max_amp, float *mix, float *noise, float *absmax,
+                 void *stream) {
+    if (!y || !snr_db || !mix || !noise || !absmax) return synth_fail("null argument");
+    if (R <= 0 || S < 2 || M <= 0 || L <= 0 || L > (1 << 30)) return synth_fail("need at least one speech source and the noise source");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_mix, dim3(M, R), dim3(256), 0, st, y, snr_db, mix, noise, absmax, S, M, (int)L);
+    hipLaunchKernelGGL(k_peak, dim3(64, R), dim3(256), 0, st, mix, absmax, M, (int)L, max_amp);
+    return hipGetLastError() == hipSuccess ? SE_OK : synth_fail("mix launch failed");
+}
+
+}  // extern "C"

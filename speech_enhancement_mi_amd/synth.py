@@ -203,6 +203,65 @@ def synth_utterances(batch: int, length: int, num_mics: int = 3, seed: int = 0,
     return mix, clean
 
 
+# ---- host restatement of the GPU data generator (csrc/se_synth.hip): the checker of tests/test_synth_gen.py ----
+
+def _image_axis(n: np.ndarray, L: float, xs: float, b0: float, b1: float):
+    """Image n of a source at xs in a room [0, L]: position and the product of the wall reflection coefficients."""
+    an = np.abs(n)
+    even = (an % 2) == 0
+    pos = np.where(even, n * L + xs, (n + 1) * L - xs)
+    r0 = np.where(even, an // 2, np.where(n > 0, (an - 1) // 2, (an + 1) // 2))
+    r1 = np.where(even, an // 2, np.where(n > 0, (an + 1) // 2, (an - 1) // 2))
+    return pos, np.power(b0, r0) * np.power(b1, r1)
+
+
+def image_rir(room, beta, src, mic, nb_img, fs=16000.0, c=343.0, length=4096):
+    """Image-source room impulse response of ONE source / microphone pair (what gpuRIR.simulateRIR computes before its
+    diffuse-tail model; multichannel.py:83-93): sum over images of prod(beta^reflections) / (4 pi d) at the fractional delay
+    d fs / c through a Hann-windowed sinc of Tw = 8 ms."""
+    Tw = int(round(8e-3 * fs))
+    Tw += Tw & 1
+    nx, ny, nz = nb_img
+    px, ax = _image_axis(np.arange(nx) - nx // 2, room[0], src[0], beta[0], beta[1])
+    py, ay = _image_axis(np.arange(ny) - ny // 2, room[1], src[1], beta[2], beta[3])
+    pz, az = _image_axis(np.arange(nz) - nz // 2, room[2], src[2], beta[4], beta[5])
+    d = np.sqrt((px[:, None, None] - mic[0]) ** 2 + (py[None, :, None] - mic[1]) ** 2 + (pz[None, None, :] - mic[2]) ** 2).ravel()
+    amp = (ax[:, None, None] * ay[None, :, None] * az[None, None, :]).ravel() / (4 * np.pi * np.maximum(d, 1e-3))
+    tau = d * fs / c
+    h = np.zeros(length, np.float64)
+    k0 = np.ceil(tau - Tw / 2).astype(np.int64)
+    for j in range(Tw + 1):
+        k = k0 + j
+        x = k - tau
+        ok = (k >= 0) & (k < length) & (x <= Tw / 2)
+        w = 0.5 * (1.0 + np.cos(2 * np.pi * x / Tw))
+        np.add.at(h, k[ok], (amp * w * np.sinc(x))[ok])
+    return h.astype(np.float32)
+
+
+def fir_filter(x: np.ndarray, h: np.ndarray) -> np.ndarray:
+    """y[n] = sum_k h[k] x[n - k], truncated to len(x) (gpuRIR.simulateTrajectory of a static source)."""
+    from scipy.signal import fftconvolve
+    return fftconvolve(x.astype(np.float64), h.astype(np.float64))[:len(x)].astype(np.float32)
+
+
+def mix_noise(y: np.ndarray, snr_db: float, max_amp: float = 0.95):
+    """y [S][M][L], the last source is the noise: AddNoise.forward (augment.py:29-77) with per-channel mean-|x| amplitudes,
+    then the MAX_AMP guard of data_c.py:249-250.  Returns (mix [M][L], noise [M][L])."""
+    clean = y[:-1].astype(np.float64).sum(0)
+    nz = y[-1].astype(np.float64)
+    f = 1.0 / (10.0 ** (snr_db / 20.0) + 1.0)
+    ac = np.abs(clean).mean(-1, keepdims=True)
+    an = np.abs(nz).mean(-1, keepdims=True)
+    noise = nz * (f * ac / (an + 1e-8))
+    mix = (1.0 - f) * clean + noise
+    mix = mix / np.maximum(np.abs(mix).max(-1, keepdims=True), 1.0)
+    mx = np.abs(mix).max()
+    if mx >= max_amp:
+        mix = mix * max_amp / (mx + 1e-10)
+    return mix.astype(np.float32), noise.astype(np.float32)
+
+
 def si_sdr(reference: np.ndarray, estimation: np.ndarray) -> np.ndarray:
     """Scale-invariant SDR in dB, the restatable eval metric (reference metrics.py:61-85)."""
     estimation, reference = np.broadcast_arrays(estimation.astype(np.float64), reference.astype(np.float64))
