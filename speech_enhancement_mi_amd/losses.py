@@ -157,10 +157,13 @@ def _resample_batch(x, lens, P):
     padr = stride * K + W + max(P["first"]) + 8
     xp = Fn.pad(x, (padl, padr))[:, None, :]
     y = x.new_zeros(B, K * phases)
+    # One banded contraction per phase, written as strided views + a matrix-vector product instead of Fn.conv1d: MIOpen's
+    # strided 1-D convolution on a sliced input view read past the end of its allocation (GPU memory access fault in the
+    # forward or backward of this loss, depending on where the caching allocator had placed the tensor).
     for i in range(phases):
         start = padl + P["first"][i]
-        c = Fn.conv1d(xp[:, :, start:], P["w"][i][None, None, :], stride=stride)[:, 0, :K]
-        y[:, i::phases] = c
+        frames = xp[:, 0, start:].unfold(1, W, stride)[:, :K]  # [B, K, W] view: frames[b, k, j] = xp[b, start + k stride + j]
+        y[:, i::phases] = torch.matmul(frames.double(), P["w"][i].double()).to(y.dtype)  # (STOI's silent-frame selection is sensitive to the last bits)
     y = y[:, :Lo]
     return y * (torch.arange(Lo, device=x.device)[None, :] < n_out[:, None]), n_out
 

@@ -42,6 +42,7 @@ class TrainableCRN(TemporalCRN):
         self._nfft = c["n_fft"]
         self._state = None
         self._hip = False
+        self.batch_segments = True  # HIP path: every layer once over B x N segment streams (False: one segment at a time)
 
     def use_hip_kernels(self, flag=True):
         """True: convolutions, transposed convolutions, the GRU and the dense layers run forward AND backward on the
@@ -166,6 +167,73 @@ class TrainableCRN(TemporalCRN):
         Y = torch.complex(mr * re[:, 0] - mi * im[:, 0], mi * re[:, 0] + mr * im[:, 0])
         return Y, dict(buf=new_buf, h=hs)
 
+    # ---- ALL segments of a batch at once on the hand-written kernels ----
+    def _forward_all_hip(self, X, state):
+        """X [B, M, N, F, T] complex -> Y [B, N, F, T] complex.  The per-segment loop of realtime_process (CRN.py:577-586) is
+        sequential only through the GRU state: a convolution's time buffer is the PREVIOUS segment's (detached) input of the
+        same block (CRN.py:325-337), every norm is per segment, so each layer runs once over B x N streams with the history
+        tensor = the input shifted by one segment.  Same arithmetic as _forward_segment_hip, 34x fewer launches."""
+        from . import train_ops as K
+        B, M, N, Fq0, T = X.shape
+        Xs = X.permute(0, 2, 1, 3, 4).reshape(B * N, M, Fq0, T)
+        re, im = Xs.real, Xs.imag
+        ang = torch.atan(im / (re + EPS) + EPS)
+        mag = torch.sqrt(re ** 2 + im ** 2 + 1e-10)
+        x = torch.cat([mag, ang[:, :1] - ang[:, 1:]], dim=1).permute(0, 1, 3, 2).contiguous()  # [B*N, 5, T, F]
+
+        def shifted(t, first):  # history of segment n = input of segment n - 1 (state / zeros for n = 0), no gradient
+            tv = t.detach().reshape(B, N, *t.shape[1:])
+            head = first[:, None] if first is not None else torch.zeros_like(tv[:, :1])
+            return torch.cat([head, tv[:, :-1]], dim=1).reshape(t.shape)
+
+        residuals = [x]
+        new_buf = []
+        for i, blk in enumerate(self.convlist):
+            prev = shifted(x, state["buf"][i] if state["buf"] is not None else None)
+            y = K.conv_block(x, prev, blk.conv.weight, blk.conv.bias, 2 ** i)
+            new_buf.append(x.detach().reshape(B, N, *x.shape[1:])[:, -1].contiguous())
+            x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            residuals.append(x)
+        BN, C, T, Fq = x.shape
+        seq = x.permute(0, 2, 1, 3).reshape(B, N, T, C * Fq)
+        g = self.gru.sequence_model
+        hs = [state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size) for l in range(g.num_layers)]
+        outs = []
+        for n in range(N):  # the recurrence: state carried across segments, detached at every segment (CRN.py:281)
+            s = seq[:, n]
+            for l in range(g.num_layers):
+                s, hT = K.gru_layer(s, hs[l], getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"),
+                                    getattr(g, f"bias_hh_l{l}"))
+                hs[l] = hT.detach()
+            outs.append(s)
+        o = torch.stack(outs, dim=1).reshape(BN, T, -1)
+        o = torch.relu(K.linear(o, self.gru.fc_output_layer.weight, self.gru.fc_output_layer.bias))
+        o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
+        x = o.reshape(BN, T, C, Fq).permute(0, 2, 1, 3).contiguous()
+        L = len(self.deconvlist)
+
+        def conv1x1(t, mod):
+            w = mod.weight.reshape(mod.weight.shape[0], -1)
+            return K.linear(t.permute(0, 2, 3, 1), w, mod.bias).permute(0, 3, 1, 2)
+
+        for j, blk in enumerate(self.deconvlist):
+            y = K.deconv_block(x, blk.conv.weight, blk.conv.bias, 2 ** j)
+            y = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            if j < L - 1:
+                res = residuals[-2 - j]
+                if res.shape[3] > y.shape[3]:
+                    y = Fn.pad(y, (0, res.shape[3] - y.shape[3]))
+                elif res.shape[3] < y.shape[3]:
+                    y = y[..., :res.shape[3]]
+                m = torch.sigmoid(_gln(conv1x1(res, blk.residualmask), blk.residualnorm.weight, blk.residualnorm.bias))
+                y = m * torch.relu(conv1x1(res, blk.residual)) + (1.0 - m) * y
+            x = y
+        m = x.clamp(-9.9, 9.9)
+        m = -10.0 * torch.log((10.0 - m) / (10.0 + m))
+        mr, mi = m[:, 0].transpose(1, 2), m[:, 1].transpose(1, 2)  # [B*N, F, T]
+        Y = torch.complex(mr * re[:, 0] - mi * im[:, 0], mi * re[:, 0] + mr * im[:, 0])
+        return Y.reshape(B, N, *Y.shape[1:]), dict(buf=new_buf, h=hs)
+
     def realtime_process_train(self, mixture, flag=False):
         """Differentiable realtime_process (CRN.py:560-589): [B, M, L] -> [B, L]."""
         K = self.segment_length
@@ -175,14 +243,18 @@ class TrainableCRN(TemporalCRN):
             self._state = dict(buf=None, h=None)
         seg, gap = self._segment(mixture)  # [B, M, N, K]
         X = self._stft(seg)  # [B, M, N, F, T]
-        outs = []
         state = self._state
-        seg_fn = self._forward_segment_hip if self._hip else self._forward_segment
-        for n in range(X.shape[2]):
-            Y, state = seg_fn(X[:, :, n], state)
-            outs.append(self._istft(Y))
+        if self._hip and self.batch_segments:
+            Y, state = self._forward_all_hip(X, state)
+            y = self._istft(Y)  # [B, N, K]
+        else:
+            outs = []
+            seg_fn = self._forward_segment_hip if self._hip else self._forward_segment
+            for n in range(X.shape[2]):
+                Y, state = seg_fn(X[:, :, n], state)
+                outs.append(self._istft(Y))
+            y = torch.stack(outs, dim=1)  # [B, N, K]
         self._state = state
-        y = torch.stack(outs, dim=1)  # [B, N, K]
         B, N, _ = y.shape
         s1 = y[:, 0::2].reshape(B, -1)[:, P:]
         s2 = y[:, 1::2].reshape(B, -1)[:, :-P]
