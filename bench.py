@@ -331,7 +331,7 @@ def bench_train(args, rank, local_rank, world, backend):
     last = {}
 
     def step():
-        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=2, loss=args.train_loss)
+        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss)
 
     progress(f"train: {args.warmup} + {args.steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, args.steps, args.warmup, world, backend)
@@ -501,6 +501,7 @@ def parse_args(argv=None):
                     help="--mode train: hip = hand-written forward/backward kernels for conv / transposed conv / GRU (default); torch = autograd checker path")
     ap.add_argument("--train-loss", choices=["full", "sisnr"], default="full",
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
+    ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dtype", choices=sorted(PRECISIONS), default="f32",

@@ -189,12 +189,21 @@ int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, floa
                         void *stream);
 /* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU); bias may be NULL; K % 8 == 0 */
 int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream);
+/* C[Na][Nb] = sum_r A[r][i] B[r][j], both operands row-major [R][.]: dense / 1x1-convolution weight gradients over R rows */
+int se_train_gemm_tn(const float *A, const float *B, float *C, int64_t R, int Na, int Nb, void *stream);
 /* one GRU time step (CRN.py:269 nn.GRU cell), saving r, z, n, gh_n per row in `gates` for the backward pass */
 int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const float *whh, const float *bhh, float *hout, float *seq,
                       int64_t seq_ld, float *gates, int64_t gates_ld, int B, int H, void *stream);
 /* gate derivatives of one step: dh = d1 + d2 + d3 (NULL = absent) -> dgi, dgh (rows of 3H), dhz = z * dh */
 int se_train_gru_bwd_gates(const float *d1, int64_t d1_ld, const float *d2, const float *d3, const float *gates, int64_t gates_ld, const float *hprev,
                            int64_t hprev_ld, float *dgi, float *dgh, int64_t dg_ld, float *dhz, int B, int H, void *stream);
+/* all T steps of one GRU layer in one call: forward (gate values saved) and the BPTT sweep with the gradient cut at segment
+ * boundaries ((t + 1) % seg_len == 0: the carried state is detached per segment, CRN.py:281).  gi [B][T][3H], out [B][T][H],
+ * gates [B][T][4H], whh_t = W_hh^T [H][3H]; scratch: 2 B H floats (forward), 4 B H floats (backward); backward: B <= 16 */
+int se_train_gru_seq_fwd(const float *gi, const float *h0, const float *whh, const float *bhh, float *out, float *gates, float *hT, float *scratch,
+                         int B, int T, int H, void *stream);
+int se_train_gru_seq_bwd(const float *dout, const float *dhT, const float *gates, const float *out, const float *h0, const float *whh_t, float *dgi,
+                         float *dgh, float *scratch, int B, int T, int H, int seg_len, void *stream);
 
 /* ---- 8f-4: synthetic multi-microphone training data on the GPU (csrc/se_synth.hip) -------------------------------------
  * Replaces the reference's CPU/gpuRIR input pipeline for DP training: multichannel.py:37-103 (Single2Multi.simulate: shoebox

@@ -259,6 +259,152 @@ __global__ __launch_bounds__(256) void k_gru_bwd_gates(GruBwdArgs a) {
     a.dhz[i] = dh * z;
 }
 
+// C[Na][Nb] = sum_r A[r][i] B[r][j]: the weight gradient of a dense layer / 1x1 convolution, contracted over the R = streams x
+// positions rows of two ROW-major operands (no transposed copies of 20-MB activations; R up to 10^6, Na, Nb <= 128).  The rows
+// are split over blockIdx.z and the four waves; partial tiles are summed through LDS and added atomically into the zeroed C.
+struct GemmTnArgs {
+    const float *A, *B;
+    float *C;
+    long R, rows_per_split;
+    int Na, Nb;
+};
+
+__global__ __launch_bounds__(256) void k_gemm_tn_acc(GemmTnArgs a) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const long r0 = (long)blockIdx.z * a.rows_per_split, r1 = min(a.R, r0 + a.rows_per_split);
+    const int ia = min(i0 + l31, a.Na - 1), jb = min(j0 + l31, a.Nb - 1);
+    const bool ia_ok = i0 + l31 < a.Na, jb_ok = j0 + l31 < a.Nb;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    constexpr int U = 8;  // MFMA steps per trip: row r0 + 8 (U s + u) + 2 wave + kh
+    for (long base = r0 + 2 * wave + kh; base < r1; base += 8 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long row = base + 8 * u;
+            const bool ok = row < r1;
+            const long rc = ok ? row : r1 - 1;
+            av[u] = (ok && ia_ok) ? a.A[rc * a.Na + ia] : 0.0f;
+            bv[u] = (ok && jb_ok) ? a.B[rc * a.Nb + jb] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && jb_ok) {  // D layout: column (j) on the lane, rows (i) = (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (i < a.Na) atomicAdd(a.C + (long)i * a.Nb + j0 + l31, acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]);
+        }
+    }
+}
+
+// One BPTT step in ONE launch: the gate derivatives of step t for every (stream, unit) and the hand-over to step t - 1,
+//   g_t[b][k] = sum_j dgh_t[b][j] W_hh[j][k]      (w_hh_t = W_hh^T, [H][3H], K-contiguous like k_gemm_skinny's operands)
+// Every workgroup recomputes the (cheap, B x H element) gate derivatives into LDS, the owner of a 32-unit column block also
+// writes them out, then contracts its block of W_hh^T against the LDS copy (32x32x2 fp32 MFMA, K = 3H split over the four
+// waves, 12 eight-deep k blocks in flight per wave).  Replaces k_gru_bwd_gates + k_gemm_skinny (5 + 25 us, two dependent
+// launches per step) for micro-batches of up to 16 streams.
+struct GruBwdStepArgs {
+    GruBwdArgs g;        // as k_gru_bwd_gates
+    const float *whh_t;  // [H][3H]
+    float *gout;         // [B][H] = dgh_t W_hh, or null for the first step of the sequence (nobody consumes it)
+};
+constexpr int kGruBwdMaxB = 16;
+
+__global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
+    extern __shared__ __align__(16) float dl[];  // dgh_t [B][3H + 4]
+    __shared__ float red[3][16][64];
+    const GruBwdArgs &a = s.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, K = 3 * H, ldl = K + 4;
+    const int n0 = blockIdx.x * 32;
+    // four elements per thread per trip, every load of the trip issued before the first use (the trips are a chain of L2 round
+    // trips otherwise: the stores of one element fence the loads of the next)
+    const int total = a.B * H;
+    for (int i0 = tid; i0 < total; i0 += 1024) {
+        float v1[4], v2[4], v3[4], gr[4], gz[4], gn[4], gg[4], hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 256 * u, total - 1), b = i / H, j = i - b * H;
+            const float *g = a.gates + (long)b * a.gates_ld;
+            v1[u] = a.d1 ? a.d1[(long)b * a.d1_ld + j] : 0.0f;
+            v2[u] = a.d2 ? a.d2[i] : 0.0f;
+            v3[u] = a.d3 ? a.d3[i] : 0.0f;
+            gr[u] = g[j]; gz[u] = g[H + j]; gn[u] = g[2 * H + j]; gg[u] = g[3 * H + j];
+            hv[u] = a.hprev[(long)b * a.hprev_ld + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 256 * u;
+            if (i >= total) break;
+            const int b = i / H, j = i - b * H;
+            const float dh = (v1[u] + v2[u]) + v3[u];
+            const float r = gr[u], z = gz[u], n = gn[u], ghn = gg[u], hp = hv[u];
+            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+            const float da = dn * (1.0f - n * n);
+            const float dzp = dz * z * (1.0f - z);
+            const float drp = da * ghn * r * (1.0f - r);
+            float *l = dl + b * ldl;
+            l[j] = drp; l[H + j] = dzp; l[2 * H + j] = da * r;
+            if (j >= n0 && j < n0 + 32) {  // this workgroup's units: the step's outputs
+                float *gi = a.dgi + (long)b * a.dg_ld, *gh = a.dgh + (long)b * a.dg_ld;
+                gi[j] = drp; gi[H + j] = dzp; gi[2 * H + j] = da;
+                gh[j] = drp; gh[H + j] = dzp; gh[2 * H + j] = da * r;
+                a.dhz[i] = dh * z;
+            }
+        }
+    }
+    if (!s.gout) return;
+    __syncthreads();
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int nkb = K >> 3;  // 3H is a multiple of 48
+    const int kb0 = (int)((long)nkb * wave / 4), kb1 = (int)((long)nkb * (wave + 1) / 4);
+    const float *ap = dl + min(l31, a.B - 1) * ldl + 4 * kh;
+    const float *wp = s.whh_t + (long)min(n0 + l31, H - 1) * K + 4 * kh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    constexpr int PF = 12;
+    float4 qw[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) qw[i] = *reinterpret_cast<const float4 *>(wp + min(kb0 + i, nkb - 1) * 8);
+    for (int kb = kb0; kb < kb1; kb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const float4 cw = qw[i];
+            const float sc = kb + i < kb1 ? 1.0f : 0.0f;  // uniform: a slot past the wave's range contributes nothing
+            const float4 ca = *reinterpret_cast<const float4 *>(ap + min(kb + i, nkb - 1) * 8);
+            qw[i] = *reinterpret_cast<const float4 *>(wp + min(kb + i + PF, nkb - 1) * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x * sc, cw.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y * sc, cw.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z * sc, cw.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w * sc, cw.w, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && n0 + l31 < H) {  // D layout: column (unit) on the lane, rows (stream) = (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < a.B) s.gout[(long)m * H + n0 + l31] = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+        }
+    }
+}
+
 }  // namespace se
 
 extern "C" {
@@ -312,6 +458,20 @@ int se_train_gemm(const float *A, const float *W, const float *bias, float *C, i
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm launch failed");
 }
 
+/* C[Na][Nb] = sum over the R rows of A[r][i] * B[r][j] (both row-major): weight gradients without transposed copies */
+int se_train_gemm_tn(const float *A, const float *B, float *C, int64_t R, int Na, int Nb, void *stream) {
+    if (!A || !B || !C || R <= 0 || Na <= 0 || Nb <= 0) return tfail(SE_ERR_ARG, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(C, 0, (size_t)Na * Nb * sizeof(float), st) != hipSuccess) return tfail(SE_ERR_HIP, "memset failed");
+    const int tiles = ((Na + 31) / 32) * ((Nb + 31) / 32);
+    long nsplit = std::max<long>(1, std::min<long>((R + 255) / 256, (4 * 256 + tiles - 1) / tiles));  // ~4 workgroups per CU, >= 256 rows each
+    const long rows_per_split = ((R + nsplit - 1) / nsplit + 7) / 8 * 8;
+    nsplit = (R + rows_per_split - 1) / rows_per_split;
+    se::GemmTnArgs a{A, B, C, (long)R, rows_per_split, Na, Nb};
+    hipLaunchKernelGGL(se::k_gemm_tn_acc, dim3((Nb + 31) / 32, (Na + 31) / 32, (unsigned)nsplit), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm_tn launch failed");
+}
+
 int se_train_gru_step(const float *gi, int64_t gi_ld, const float *hprev, const float *whh, const float *bhh, float *hout, float *seq,
                       int64_t seq_ld, float *gates, int64_t gates_ld, int B, int H, void *stream) {
     if (!gi || !hprev || !whh || !bhh || !hout || !seq || B <= 0 || H <= 0 || H % 16) return tfail(SE_ERR_ARG, "bad argument (H must be a multiple of 16)");
@@ -326,6 +486,49 @@ int se_train_gru_bwd_gates(const float *d1, int64_t d1_ld, const float *d2, cons
     se::GruBwdArgs a{d1, d2, d3, (long)d1_ld, gates, (long)gates_ld, hprev, (long)hprev_ld, dgi, dgh, (long)dg_ld, dhz, B, H};
     hipLaunchKernelGGL(se::k_gru_bwd_gates, dim3((unsigned)(((long)B * H + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru backward launch failed");
+}
+
+/* All T steps of one GRU layer from C (one Python call instead of T): forward with the gate values saved, and the BPTT
+ * sweep with truncation at segment boundaries (the carried state is detached at every segment, CRN.py:281): the
+ * gradient is not carried from step t + 1 into step t when (t + 1) % seg_len == 0.  scratch: forward 2 * B * H floats,
+ * backward 4 * B * H floats. */
+int se_train_gru_seq_fwd(const float *gi, const float *h0, const float *whh, const float *bhh, float *out, float *gates, float *hT, float *scratch,
+                         int B, int T, int H, void *stream) {
+    if (!gi || !h0 || !whh || !bhh || !out || !gates || !hT || !scratch || B <= 0 || T <= 0 || H <= 0 || H % 16) return tfail(SE_ERR_ARG, "bad argument (H must be a multiple of 16)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *hb[2] = {scratch, scratch + (size_t)B * H};
+    if (hipMemcpyAsync(hb[0], h0, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return tfail(SE_ERR_HIP, "copy failed");
+    for (int t = 0; t < T; t++) {
+        se::GruStepArgs g{gi + (size_t)t * 3 * H, (long)T * 3 * H, hb[t & 1], whh, bhh, hb[(t + 1) & 1], out + (size_t)t * H, (long)T * H, B, H,
+                          gates + (size_t)t * 4 * H, (long)T * 4 * H};
+        hipLaunchKernelGGL(se::k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
+    }
+    if (hipMemcpyAsync(hT, hb[T & 1], (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return tfail(SE_ERR_HIP, "copy failed");
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru sequence launch failed");
+}
+
+int se_train_gru_seq_bwd(const float *dout, const float *dhT, const float *gates, const float *out, const float *h0, const float *whh_t, float *dgi,
+                         float *dgh, float *scratch, int B, int T, int H, int seg_len, void *stream) {
+    if (!dout || !gates || !out || !h0 || !whh_t || !dgi || !dgh || !scratch || B <= 0 || T <= 0 || H <= 0 || H % 16) return tfail(SE_ERR_ARG, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *zb[2] = {scratch, scratch + (size_t)B * H}, *gb[2] = {scratch + (size_t)2 * B * H, scratch + (size_t)3 * B * H};
+    if (B > se::kGruBwdMaxB) return tfail(SE_ERR_ARG, "the fused BPTT step takes up to %d streams per call (got %d): use the per-step entry points", se::kGruBwdMaxB, B);
+    const size_t lds = (size_t)B * (3 * H + 4) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se::k_gru_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    if (lds > 128 * 1024) return tfail(SE_ERR_ARG, "hidden size %d too large for the fused BPTT step", H);
+    for (int t = T - 1; t >= 0; t--) {
+        const bool last = t == T - 1, cut = !last && seg_len > 0 && (t + 1) % seg_len == 0;
+        const float *d2 = last ? dhT : (cut ? nullptr : zb[(t + 1) & 1]);
+        const float *d3 = (last || cut) ? nullptr : gb[(t + 1) & 1];
+        const float *hp = t == 0 ? h0 : out + (size_t)(t - 1) * H;
+        const long hp_ld = t == 0 ? H : (long)T * H;
+        se::GruBwdArgs a{dout + (size_t)t * H, d2, d3, (long)T * H, gates + (size_t)t * 4 * H, (long)T * 4 * H, hp, hp_ld,
+                         dgi + (size_t)t * 3 * H, dgh + (size_t)t * 3 * H, (long)T * 3 * H, zb[t & 1], B, H};
+        se::GruBwdStepArgs s{a, whh_t, t > 0 ? gb[t & 1] : nullptr};
+        hipLaunchKernelGGL(se::k_gru_bwd_step, dim3((H + 31) / 32), dim3(256), lds, st, s);
+    }
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru backward sequence launch failed");
 }
 
 }  // extern "C"

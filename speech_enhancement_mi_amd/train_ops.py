@@ -194,6 +194,17 @@ def _gemm(A, W, bias=None, act=0):
     return out
 
 
+def _gemm_tn(A, B):
+    """sum_r A[r, :]^T B[r, :] -> [Na, Nb] (row-major operands; the contraction runs over the rows)"""
+    A, B = A.contiguous(), B.contiguous()
+    R, Na = A.shape
+    Nb = B.shape[1]
+    out = torch.empty(Na, Nb, device=A.device, dtype=torch.float32)
+    with _Timed("k_gemm_tn_acc", 2.0 * R * Na * Nb):
+        _chk(_lib().se_train_gemm_tn(_p(A), _p(B), _p(out), R, Na, Nb, _st()))
+    return out
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
@@ -208,17 +219,19 @@ class _LinearFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         dx = _gemm(dy2, w.t().contiguous()).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
-        dw = _gemm(dy2.t().contiguous(), x2.t().contiguous()) if ctx.needs_input_grad[1] else None
+        dw = _gemm_tn(dy2, x2) if ctx.needs_input_grad[1] else None
         db = dy2.sum(0) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
 class _GruLayerFn(torch.autograd.Function):
     """One GRU layer, batch_first: x [B, T, In], h0 [B, H] (a constant: the carried state is detached, CRN.py:281) ->
-    (out [B, T, H], hT [B, H])."""
+    (out [B, T, H], hT [B, H]).  seg_len > 0: the sequence is a chain of segments of seg_len steps whose carried state is
+    detached at every seam, so the backward sweep drops the gradient that would cross a seam (truncated BPTT exactly as the
+    per-segment loop of CRN.py:577-586 does it).  The time loops run inside the library (se_train_gru_seq_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, seg_len):
         _need_gpu(x, w_ih)
         lib = _lib()
         B, T, In = x.shape
@@ -227,49 +240,52 @@ class _GruLayerFn(torch.autograd.Function):
         gi = _gemm(x2, w_ih, b_ih.contiguous())  # [B*T, 3H]
         out = torch.empty(B, T, H, device=x.device, dtype=torch.float32)
         gates = torch.empty(B, T, 4 * H, device=x.device, dtype=torch.float32)
-        hbuf = [h0.contiguous().clone(), torch.empty(B, H, device=x.device, dtype=torch.float32)]
-        w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
-        st = _st()
-        for t in range(T):
-            hp, hn = hbuf[t & 1], hbuf[(t + 1) & 1]
-            with _Timed("k_gru_step", 2.0 * B * 3 * H * H):
-                _chk(lib.se_train_gru_step(C.c_void_p(gi.data_ptr() + 4 * t * 3 * H), T * 3 * H, _p(hp), _p(w_hh_c), _p(b_hh_c), _p(hn),
-                                           C.c_void_p(out.data_ptr() + 4 * t * H), T * H, C.c_void_p(gates.data_ptr() + 4 * t * 4 * H), T * 4 * H, B, H, st))
-        hT = hbuf[T & 1].clone()
-        ctx.save_for_backward(x2, h0.contiguous(), w_ih, w_hh_c, out, gates)
-        ctx.dims = (B, T, In, H)
+        hT = torch.empty(B, H, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(2, B, H, device=x.device, dtype=torch.float32)
+        h0c, w_hh_c, b_hh_c = h0.contiguous(), w_hh.contiguous(), b_hh.contiguous()
+        with _Timed("k_gru_step", 2.0 * B * 3 * H * H * T):
+            _chk(lib.se_train_gru_seq_fwd(_p(gi), _p(h0c), _p(w_hh_c), _p(b_hh_c), _p(out), _p(gates), _p(hT), _p(scratch), B, T, H, _st()))
+        ctx.save_for_backward(x2, h0c, w_ih, w_hh_c, out, gates)
+        ctx.dims = (B, T, In, H, int(seg_len))
         return out, hT
 
     @staticmethod
     def backward(ctx, dout, dhT):
         x2, h0, w_ih, w_hh, out, gates = ctx.saved_tensors
         lib = _lib()
-        B, T, In, H = ctx.dims
+        B, T, In, H, seg_len = ctx.dims
         dout = dout.contiguous()
         dgi = torch.empty(B, T, 3 * H, device=out.device, dtype=torch.float32)
         dgh = torch.empty(B, T, 3 * H, device=out.device, dtype=torch.float32)
-        dhz = torch.empty(B, H, device=out.device, dtype=torch.float32)
-        w_hh_t = w_hh.t().contiguous()  # [H, 3H]: dh_{t-1} += dgh W_hh as a K-contiguous GEMM
-        st = _st()
-        carry_z, carry_g = (dhT.contiguous() if dhT is not None else None), None
-        for t in range(T - 1, -1, -1):
-            hprev = h0 if t == 0 else out[:, t - 1]
-            hp_ptr = C.c_void_p(h0.data_ptr()) if t == 0 else C.c_void_p(out.data_ptr() + 4 * (t - 1) * H)
-            hp_ld = H if t == 0 else T * H
-            _chk(lib.se_train_gru_bwd_gates(C.c_void_p(dout.data_ptr() + 4 * t * H), T * H, _p(carry_z), _p(carry_g),
-                                            C.c_void_p(gates.data_ptr() + 4 * t * 4 * H), T * 4 * H, hp_ptr, hp_ld,
-                                            C.c_void_p(dgi.data_ptr() + 4 * t * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * t * 3 * H), T * 3 * H,
-                                            _p(dhz), B, H, st))
-            carry_z = dhz.clone()
-            if t > 0:
-                carry_g = _gemm(dgh[:, t].contiguous(), w_hh_t)  # [B, H]
-            del hprev
+        w_hh_t = w_hh.t().contiguous()  # [H, 3H]: dh_{t-1} += dgh W_hh with K-contiguous operands
+        if B <= 16:
+            scratch = torch.empty(4, B, H, device=out.device, dtype=torch.float32)
+            dhT_c = dhT.contiguous() if dhT is not None else None
+            with _Timed("k_gru_bwd_step", 2.0 * B * 3 * H * H * T):
+                _chk(lib.se_train_gru_seq_bwd(_p(dout), _p(dhT_c), _p(gates), _p(out), _p(h0), _p(w_hh_t), _p(dgi), _p(dgh), _p(scratch), B, T, H,
+                                              seg_len, _st()))
+        else:  # wide batches: gate kernel + GEMM per step
+            dhz = torch.empty(B, H, device=out.device, dtype=torch.float32)
+            st = _st()
+            carry_z, carry_g = (dhT.contiguous() if dhT is not None else None), None
+            for t in range(T - 1, -1, -1):
+                hp_ptr = C.c_void_p(h0.data_ptr()) if t == 0 else C.c_void_p(out.data_ptr() + 4 * (t - 1) * H)
+                hp_ld = H if t == 0 else T * H
+                _chk(lib.se_train_gru_bwd_gates(C.c_void_p(dout.data_ptr() + 4 * t * H), T * H, _p(carry_z), _p(carry_g),
+                                                C.c_void_p(gates.data_ptr() + 4 * t * 4 * H), T * 4 * H, hp_ptr, hp_ld,
+                                                C.c_void_p(dgi.data_ptr() + 4 * t * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * t * 3 * H), T * 3 * H,
+                                                _p(dhz), B, H, st))
+                if t > 0 and seg_len > 0 and t % seg_len == 0:
+                    carry_z, carry_g = None, None  # segment seam: the state entering step t was detached
+                else:
+                    carry_z = dhz.clone()
+                    carry_g = _gemm(dgh[:, t].contiguous(), w_hh_t) if t > 0 else None
         dgi2, dgh2 = dgi.reshape(B * T, 3 * H), dgh.reshape(B * T, 3 * H)
         hprev_all = torch.cat([h0[:, None], out[:, :-1]], dim=1).reshape(B * T, H)
         dx = _gemm(dgi2, w_ih.t().contiguous()).reshape(B, T, In) if ctx.needs_input_grad[0] else None
-        dw_ih = _gemm(dgi2.t().contiguous(), x2.t().contiguous())
-        dw_hh = _gemm(dgh2.t().contiguous(), hprev_all.t().contiguous())
-        return dx, None, dw_ih, dw_hh, dgi2.sum(0), dgh2.sum(0)
+        dw_ih = _gemm_tn(dgi2, x2)
+        dw_hh = _gemm_tn(dgh2, hprev_all)
+        return dx, None, dw_ih, dw_hh, dgi2.sum(0), dgh2.sum(0), None
 
 
 def conv_block(x, xprev, w, b, dilation):
@@ -284,5 +300,5 @@ def linear(x, w, b):
     return _LinearFn.apply(x, w, b)
 
 
-def gru_layer(x, h0, w_ih, w_hh, b_ih, b_hh):
-    return _GruLayerFn.apply(x, h0, w_ih, w_hh, b_ih, b_hh)
+def gru_layer(x, h0, w_ih, w_hh, b_ih, b_hh, seg_len=0):
+    return _GruLayerFn.apply(x, h0, w_ih, w_hh, b_ih, b_hh, seg_len)

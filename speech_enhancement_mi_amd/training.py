@@ -195,18 +195,16 @@ class TrainableCRN(TemporalCRN):
             x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
             residuals.append(x)
         BN, C, T, Fq = x.shape
-        seq = x.permute(0, 2, 1, 3).reshape(B, N, T, C * Fq)
+        seq = x.permute(0, 2, 1, 3).reshape(B, N * T, C * Fq)
         g = self.gru.sequence_model
-        hs = [state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size) for l in range(g.num_layers)]
-        outs = []
-        for n in range(N):  # the recurrence: state carried across segments, detached at every segment (CRN.py:281)
-            s = seq[:, n]
-            for l in range(g.num_layers):
-                s, hT = K.gru_layer(s, hs[l], getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"),
-                                    getattr(g, f"bias_hh_l{l}"))
-                hs[l] = hT.detach()
-            outs.append(s)
-        o = torch.stack(outs, dim=1).reshape(BN, T, -1)
+        hs = []
+        for l in range(g.num_layers):  # the recurrence: ONE pass over the N * T steps of every utterance; the carried state is
+            # detached at every segment seam (CRN.py:281), which seg_len = T reproduces in the backward sweep
+            h0 = state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size)
+            seq, hT = K.gru_layer(seq, h0, getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"),
+                                  getattr(g, f"bias_hh_l{l}"), seg_len=T)
+            hs.append(hT.detach())
+        o = seq.reshape(BN, T, -1)
         o = torch.relu(K.linear(o, self.gru.fc_output_layer.weight, self.gru.fc_output_layer.bias))
         o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
         x = o.reshape(BN, T, C, Fq).permute(0, 2, 1, 3).contiguous()
