@@ -320,6 +320,101 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {
 // (coalesced) and all NTAP loads of a channel are independent, so the memory system stays full; an LDS patch (as in
 // k_conv_igemm) would re-stage a time-tap halo several times larger than the rows a workgroup produces.
 // Weights [tap][ci][4*W4] sit in LDS and are read as broadcast float4.
+// The 5x5 frequency-dilated pre-conv blocks of CRN_ELU / the student (CRN_ELU.py:335-340: CO -> CO channels, taps (kf, kt),
+// time rows t-4..t, columns f + (kf - 2) fd) on the vector ALU, TWO consecutive time rows per thread: the outputs at t and
+// t + 1 share four of their five tap rows, so a thread loads 6 rows x 5 columns per channel for both (150 loads instead of
+// 250), every weight read from LDS feeds both outputs (half the broadcast reads of k_conv_small) and exactly CO accumulators
+// per output are kept (625 FMAs per output instead of 1000).  Weights [25][Ci][8] and the fused gated pair as k_conv_small.
+template <int CO>
+__global__ __launch_bounds__(256) void k_preconv_tb(ConvArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int nw = 25 * a.Ci * 8;
+    for (int i = tid; i < nw; i += 256) lds[i] = a.w[i];
+    float *gl = lds + nw;
+    const int ng = 2 * CO * CO + 2 * CO;
+    for (int i = tid; i < ng; i += 256) gl[i] = a.gatew[i];
+    __syncthreads();
+    const int F = a.FP, TP = (a.T + 1) >> 1;  // row pairs
+    const int p = blockIdx.x * 256 + tid;
+    const bool live = p < TP * F;
+    const int pc = live ? p : TP * F - 1;
+    const int tp = pc / F, f = pc - tp * F, t0 = 2 * tp;
+    const bool two = t0 + 1 < a.T;
+    const long xs_c = (long)a.T * a.Fi;
+    const float *xb = a.x + (long)b * a.Ci * xs_c;
+    const float *xpb = a.xprev ? a.xprev + (long)b * a.Ci * xs_c : nullptr;
+    // rows t0-4 .. t0+1 (history rows from the previous slot), columns f + coloff[kf * 5] - colpad
+    const float *rowp[6];
+    bool rok[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int ts = t0 - 4 + j;
+        const bool hist = ts < 0;
+        rok[j] = hist ? (xpb != nullptr && ts + a.T >= 0) : ts < a.T;
+        const int tsc = min(max(hist ? ts + a.T : ts, 0), a.T - 1);
+        rowp[j] = (hist && xpb ? xpb : xb) + (long)tsc * a.Fi;
+    }
+    int col[5];
+    bool cok[5];
+#pragma unroll
+    for (int kf = 0; kf < 5; kf++) {
+        const int fi = f + a.coloff[kf * 5] - a.colpad;
+        cok[kf] = fi >= 0 && fi < a.Fi;
+        col[kf] = min(max(fi, 0), a.Fi - 1);
+    }
+    float acc0[CO], acc1[CO];
+#pragma unroll
+    for (int j = 0; j < CO; j++) acc0[j] = acc1[j] = 0.0f;
+    for (int c = 0; c < a.Ci; c++) {
+#pragma unroll
+        for (int kf = 0; kf < 5; kf++) {
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = rowp[j][c * xs_c + col[kf]];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = (rok[j] && cok[kf]) ? v[j] : 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 5; kt++) {
+                const float *w = lds + ((kf * 5 + kt) * a.Ci + c) * 8;
+                const float4 w4 = *reinterpret_cast<const float4 *>(w);
+                float wv[8] = {w4.x, w4.y, w4.z, w4.w, 0, 0, 0, 0};
+                if (CO > 4) {
+                    const float4 w5 = *reinterpret_cast<const float4 *>(w + 4);
+                    wv[4] = w5.x; wv[5] = w5.y; wv[6] = w5.z; wv[7] = w5.w;
+                }
+#pragma unroll
+                for (int j = 0; j < CO; j++) { acc0[j] += wv[j] * v[kt]; acc1[j] += wv[j] * v[kt + 1]; }
+            }
+        }
+    }
+    const long ys_c = (long)a.T * a.Fy;
+    float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        float val[CO], outv[CO];
+#pragma unroll
+        for (int co = 0; co < CO; co++) val[co] = conv_act((o ? acc1[co] : acc0[co]) + a.bias[co], a.act);
+#pragma unroll
+        for (int co = 0; co < CO; co++) {  // out = conv_trans(v) * sigmoid(conv_gated(v))  (CRN_ELU.py:240)
+            float tr = gl[2 * CO * CO + co], gt = gl[2 * CO * CO + CO + co];
+#pragma unroll
+            for (int j = 0; j < CO; j++) { tr += gl[co * CO + j] * val[j]; gt += gl[CO * CO + co * CO + j] * val[j]; }
+            outv[co] = tr * (1.0f / (1.0f + expf(-gt)));
+        }
+        if (live && (o == 0 || two)) {
+            float *yp = a.y + ((long)b * a.Cy + a.cy0) * ys_c + (long)(t0 + o) * a.Fy + f + a.oo;
+#pragma unroll
+            for (int co = 0; co < CO; co++) {
+                yp[co * ys_c] = outv[co];
+                if (co >= a.stats_lo && co < a.stats_hi) { ssum += outv[co]; ssq += outv[co] * outv[co]; }
+            }
+        }
+    }
+    __syncthreads();  // weights no longer needed: lds doubles as the reduction scratch
+    if (a.stats) conv_stats_store(a, ssum, ssq, lds, b);
+}
+
 template <int NTAP, int W4>
 __global__ __launch_bounds__(256) void k_conv_small(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];

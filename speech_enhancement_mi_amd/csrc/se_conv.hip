@@ -32,7 +32,16 @@ int conv_igemm_launch(int ntap, int NT, int CoPad, dim3 grid, size_t lds, hipStr
                     else hipLaunchKernelGGL((k_conv_small<NTAP_, 4>), grid, dim3(256), lds, st, a); return 0;
     switch (ntap * 8 + NT) {
         SE_CONV_TAPS(15) SE_CONV_TAPS(9) SE_CONV_TAPS(6) SE_CONV_TAPS(1)
-        case 25 * 8: hipLaunchKernelGGL((k_conv_small<25, 2>), grid, dim3(256), lds, st, a); return 0;
+        case 25 * 8: {
+            // the pre-conv blocks in their reference geometry (5 channels = 3 microphones, stride 1, time taps t-4..t, the fused
+            // gated pair, all channels activated): two time rows per thread; anything else on the general small kernel
+            bool std5 = a.Co == 5 && a.Ci == 5 && CoPad == 8 && a.s == 1 && a.os == 1 && a.dil == 1 && a.tlo_off == -4 && a.gatew != nullptr &&
+                        a.relu_lo == 0 && a.relu_hi >= 5 && a.Fi == a.FP;
+            for (int k = 0; k < 25 && std5; k++) std5 = a.rowgrp[k] == k % 5 && a.coloff[k] == a.coloff[(k / 5) * 5];
+            if (std5) hipLaunchKernelGGL((k_preconv_tb<5>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((k_conv_small<25, 2>), grid, dim3(256), lds, st, a);
+            return 0;
+        }
         default: return 1;
     }
 #undef SE_CONV_TAPS

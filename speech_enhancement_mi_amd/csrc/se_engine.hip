@@ -760,11 +760,14 @@ int launch_gln_ew(se_engine *e, const float *x, float *y, const float *w, const 
                   int mode, int C, int T, int F, hipStream_t st, const float *res = nullptr) {
     ProfScope ps(e, "k_gln_ew", "gln", 0, st);
     GlnEwArgs g{x, y, w, b, SlabStats{slab, nslot, n, e->eps_mode}, mode, C, T, F, res};
+    // grid-stride loop: about 8 workgroups per CU over the whole batch (every workgroup first reduces the producer's partial
+    // statistics, so thousands of 4-element-per-thread workgroups per launch spent their time there)
+    const int want = std::max(1, (8 * e->num_cu + e->B - 1) / e->B);
     if (n % 4 == 0) {
-        const int gx = (int)((n / 4 + 256 * 4 - 1) / (256 * 4));
+        const int gx = std::min((int)((n / 4 + 255) / 256), want);
         hipLaunchKernelGGL(k_gln_ew<4>, dim3(gx, e->B), dim3(256), 0, st, g);
     } else {
-        const int gx = (int)((n + 256 * 4 - 1) / (256 * 4));
+        const int gx = std::min((int)((n + 255) / 256), want);
         hipLaunchKernelGGL(k_gln_ew<1>, dim3(gx, e->B), dim3(256), 0, st, g);
     }
     HIPCHECK(e, hipGetLastError());
