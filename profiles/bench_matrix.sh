@@ -14,7 +14,6 @@ PY
 run crn_f32_default
 run crn_bf16x3 --dtype bf16x3 --no-cpu-baseline
 run crn_f16 --dtype f16 --no-cpu-baseline
-run crn_f32_serial --no-cpu-baseline
 run crn_nfft400 --nfft 400 --no-cpu-baseline
 run crn_b1024 --batch 1024 --no-cpu-baseline
 run crn_b1 --batch 1 --steps 20 --warmup 3 --no-cpu-baseline
@@ -24,3 +23,5 @@ run student_b1024_f16 --model student --batch 1024 --dtype f16 --no-cpu-baseline
 run crn_elu --model crn_elu --no-cpu-baseline
 run fullsubnet --model fullsubnet --no-cpu-baseline
 run train_hip --mode train --no-cpu-baseline
+run train_hip_accum1 --mode train --accum 1 --no-cpu-baseline
+run crn_elu_bf16x3 --model crn_elu --dtype bf16x3 --no-cpu-baseline
