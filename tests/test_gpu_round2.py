@@ -410,3 +410,27 @@ def test_segment_batched_training_forward_equals_per_segment():
         res[batched] = (y1.detach().cpu(), y2.detach().cpu(), torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()]).cpu())
     assert _rel(res[True][0], res[False][0]) < 1e-6 and _rel(res[True][1], res[False][1]) < 1e-6
     assert _rel(res[True][2], res[False][2]) < 5e-5  # weight gradients summed over all segments at once: fp32 summation order
+
+
+@pytest.mark.parametrize("pre_p", ["0", "1"])
+def test_reset_single_stream_student_plane_path(monkeypatch, pre_p):
+    """se_reset_stream on the student (pre-conv rings of the plane path with SE_PRE_P=1, fp32 pre-conv buffers otherwise):
+    after resetting stream 1 only, stream 1 behaves like a freshly reset engine and stream 0 like an untouched one."""
+    from test_gpu_parity import STUDENT400, _engine_v, _cuda, rel_rms
+    monkeypatch.setenv("SE_PRE_P", pre_p)
+    e, e_fresh, e_cont = (_engine_v(STUDENT400, 2, seed=3) for _ in range(3))
+    a, _ = synth.synth_utterances(2, 3200 * 3, 3, seed=41)
+    bnew, _ = synth.synth_utterances(1, 3200 * 2, 3, seed=42)
+    e.reset(2); e_cont.reset(2); e_fresh.reset(1)
+    for k in range(3):
+        w = _cuda(a[:, :, 3200 * k:3200 * (k + 1)])
+        e.step(w); e_cont.step(w)
+    e.reset_stream(1)
+    for k in range(2):
+        w0 = a[:1, :, 3200 * k:3200 * (k + 1)]
+        w1 = bnew[:, :, 3200 * k:3200 * (k + 1)]
+        y = e.step(_cuda(np.concatenate([w0, w1], 0))).cpu().numpy()
+        y_cont = e_cont.step(_cuda(np.concatenate([w0, w0], 0))).cpu().numpy()
+        y_fresh = e_fresh.step(_cuda(w1)).cpu().numpy()
+        assert rel_rms(y[1], y_fresh[0]) < 2e-6, k
+        assert np.array_equal(y[0], y_cont[0]), k
