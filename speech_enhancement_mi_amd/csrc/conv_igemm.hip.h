@@ -329,6 +329,13 @@ template <int CO>
 __global__ __launch_bounds__(256) void k_preconv_tb(ConvArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, b = blockIdx.y;
+    if ((int)blockIdx.x * 256 >= ((a.T + 1) >> 1) * a.FP) {  // the launch grid is sized for one output per thread: the second half of the
+        if (a.stats && tid == 0) {                            // workgroups has no row pair left and only reports empty statistics
+            float *o = a.stats + ((long)b * a.stats_nslot + a.stats_slot0 + blockIdx.x) * 2;
+            o[0] = 0.0f; o[1] = 0.0f;
+        }
+        return;
+    }
     const int nw = 25 * a.Ci * 8;
     for (int i = tid; i < nw; i += 256) lds[i] = a.w[i];
     float *gl = lds + nw;
