@@ -501,14 +501,18 @@ struct GruStepArgs {
 struct GruStepMulti { GruStepArgs a[4]; };
 
 __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
-    __shared__ float red[2][3][4][64];
+    __shared__ float red[3][3][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rt = wave & 1, kh = wave >> 1;
+    // 32 streams per workgroup: waves = 2 row tiles x 2 halves of K.  A batch of <= 16 streams (se_step at small batch, the
+    // training micro-batches) has one row tile: all four waves split K instead, which halves the chain of dependent L2 round
+    // trips of a step (8 k blocks per wave instead of 16 at H = 512)
+    const bool narrow = a.B <= 16;  // uniform
+    const int rt = narrow ? 0 : (wave & 1), kh = narrow ? wave : (wave >> 1), nsplit = narrow ? 4 : 2;
     const int l15 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32 + rt * 16;
     const int H = a.H;          // multiple of 16 (host-checked): every 16-deep k block is complete
     const int nkb = H >> 4;
-    const int kb0 = kh ? (nkb >> 1) : 0, kb1 = kh ? nkb : (nkb >> 1);
+    const int kb0 = nkb * kh / nsplit, kb1 = nkb * (kh + 1) / nsplit;
     // out-of-range rows / hidden units read a clamped (valid) address; their results are never stored
     const int arow = min(r0 + l15, a.B - 1);
     const int n = n0 + l15;
@@ -554,12 +558,14 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, c2.w, acc2, 0, 0, 0);
         }
     }
-    if (kh == 1) {
+    // partial sums of the other K shares: slot = wave - 1 for a narrow batch (waves 1..3 -> wave 0), the row tile otherwise
+    if (kh > 0) {
+        const int slot = narrow ? kh - 1 : rt;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            red[rt][0][r][lane] = acc0[r];
-            red[rt][1][r][lane] = acc1[r];
-            red[rt][2][r][lane] = acc2[r];
+            red[slot][0][r][lane] = acc0[r];
+            red[slot][1][r][lane] = acc1[r];
+            red[slot][2][r][lane] = acc2[r];
         }
     }
     __syncthreads();
@@ -569,9 +575,16 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
         for (int r = 0; r < 4; r++) {
             const int row = r0 + kq * 4 + r;  // D layout: col = lane&15, row = (lane>>4)*4 + reg
             if (row >= a.B) continue;
-            const float gh_r = acc0[r] + red[rt][0][r][lane] + bh_r;
-            const float gh_z = acc1[r] + red[rt][1][r][lane] + bh_z;
-            const float gh_n = acc2[r] + red[rt][2][r][lane] + bh_n;
+            const int s0 = narrow ? 0 : rt;
+            float p0 = red[s0][0][r][lane], p1 = red[s0][1][r][lane], p2 = red[s0][2][r][lane];
+            if (narrow) {
+                p0 += red[1][0][r][lane] + red[2][0][r][lane];
+                p1 += red[1][1][r][lane] + red[2][1][r][lane];
+                p2 += red[1][2][r][lane] + red[2][2][r][lane];
+            }
+            const float gh_r = acc0[r] + p0 + bh_r;
+            const float gh_z = acc1[r] + p1 + bh_z;
+            const float gh_n = acc2[r] + p2 + bh_n;
             const float *gi = a.gi + (long)row * a.gi_ld;
             const float rg = 1.0f / (1.0f + expf(-(gi[n] + gh_r)));
             const float zg = 1.0f / (1.0f + expf(-(gi[H + n] + gh_z)));

@@ -893,7 +893,8 @@ int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlappe
         }
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
         const dim3 grid((H + 15) / 16, (B + 31) / 32);
-        const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : overlapped;
+        // (<= 16 streams: the register-streaming kernel splits K over all four waves and beats the LDS-slice kernel: 9.3 vs 10.4 us)
+        const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : (overlapped || B <= 16);
         if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
         else if (H == 128 && !direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
         else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
