@@ -321,9 +321,11 @@ struct GruBwdStepArgs {
 };
 constexpr int kGruBwdMaxB = 16;
 
-__global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
+constexpr int kGruBwdWaves = 8;  // K = 3H split over eight waves: 24 eight-deep k blocks per wave at H = 512 = two rounds of 12 in flight
+
+__global__ __launch_bounds__(kGruBwdWaves * 64) void k_gru_bwd_step(GruBwdStepArgs s) {
     extern __shared__ __align__(16) float dl[];  // dgh_t [B][3H + 4]
-    __shared__ float red[3][16][64];
+    __shared__ float red[kGruBwdWaves - 1][16][64];
     const GruBwdArgs &a = s.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, K = 3 * H, ldl = K + 4;
@@ -331,11 +333,12 @@ __global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
     // four elements per thread per trip, every load of the trip issued before the first use (the trips are a chain of L2 round
     // trips otherwise: the stores of one element fence the loads of the next)
     const int total = a.B * H;
-    for (int i0 = tid; i0 < total; i0 += 1024) {
+    constexpr int NTH = kGruBwdWaves * 64;
+    for (int i0 = tid; i0 < total; i0 += 4 * NTH) {
         float v1[4], v2[4], v3[4], gr[4], gz[4], gn[4], gg[4], hv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = min(i0 + 256 * u, total - 1), b = i / H, j = i - b * H;
+            const int i = min(i0 + NTH * u, total - 1), b = i / H, j = i - b * H;
             const float *g = a.gates + (long)b * a.gates_ld;
             v1[u] = a.d1 ? a.d1[(long)b * a.d1_ld + j] : 0.0f;
             v2[u] = a.d2 ? a.d2[i] : 0.0f;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = i0 + 256 * u;
+            const int i = i0 + NTH * u;
             if (i >= total) break;
             const int b = i / H, j = i - b * H;
             const float dh = (v1[u] + v2[u]) + v3[u];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
     __syncthreads();
     const int l31 = lane & 31, kh = lane >> 5;
     const int nkb = K >> 3;  // 3H is a multiple of 48
-    const int kb0 = (int)((long)nkb * wave / 4), kb1 = (int)((long)nkb * (wave + 1) / 4);
+    const int kb0 = (int)((long)nkb * wave / kGruBwdWaves), kb1 = (int)((long)nkb * (wave + 1) / kGruBwdWaves);
     const float *ap = dl + min(l31, a.B - 1) * ldl + 4 * kh;
     const float *wp = s.whh_t + (long)min(n0 + l31, H - 1) * K + 4 * kh;
     f32x16 acc;
@@ -400,7 +403,12 @@ __global__ __launch_bounds__(256) void k_gru_bwd_step(GruBwdStepArgs s) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (m < a.B) s.gout[(long)m * H + n0 + l31] = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+            if (m < a.B) {
+                float v = acc[r];
+#pragma unroll
+                for (int w = 0; w < kGruBwdWaves - 1; w++) v += red[w][r][lane];
+                s.gout[(long)m * H + n0 + l31] = v;
+            }
         }
     }
 }
@@ -526,7 +534,7 @@ int se_train_gru_seq_bwd(const float *dout, const float *dhT, const float *gates
         se::GruBwdArgs a{dout + (size_t)t * H, d2, d3, (long)T * H, gates + (size_t)t * 4 * H, (long)T * 4 * H, hp, hp_ld,
                          dgi + (size_t)t * 3 * H, dgh + (size_t)t * 3 * H, (long)T * 3 * H, zb[t & 1], B, H};
         se::GruBwdStepArgs s{a, whh_t, t > 0 ? gb[t & 1] : nullptr};
-        hipLaunchKernelGGL(se::k_gru_bwd_step, dim3((H + 31) / 32), dim3(256), lds, st, s);
+        hipLaunchKernelGGL(se::k_gru_bwd_step, dim3((H + 31) / 32), dim3(se::kGruBwdWaves * 64), lds, st, s);
     }
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru backward sequence launch failed");
 }
