@@ -500,14 +500,15 @@ struct GruStepArgs {
 // same shape and no gate pre-activation has to be recomputed), which halves the chain of dependent launches per segment.
 struct GruStepMulti { GruStepArgs a[4]; };
 
+template <int NW>
 __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
-    __shared__ float red[3][3][4][64];
+    __shared__ float red[NW - 1][3][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 32 streams per workgroup: waves = 2 row tiles x 2 halves of K.  A batch of <= 16 streams (se_step at small batch, the
     // training micro-batches) has one row tile: all four waves split K instead, which halves the chain of dependent L2 round
     // trips of a step (8 k blocks per wave instead of 16 at H = 512)
     const bool narrow = a.B <= 16;  // uniform
-    const int rt = narrow ? 0 : (wave & 1), kh = narrow ? wave : (wave >> 1), nsplit = narrow ? 4 : 2;
+    const int rt = narrow ? 0 : (wave & 1), kh = narrow ? wave : (wave >> 1), nsplit = narrow ? NW : 2;  // (NW = 8 only with narrow batches)
     const int l15 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32 + rt * 16;
     const int H = a.H;          // multiple of 16 (host-checked): every 16-deep k block is complete
@@ -578,9 +579,8 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
             const int s0 = narrow ? 0 : rt;
             float p0 = red[s0][0][r][lane], p1 = red[s0][1][r][lane], p2 = red[s0][2][r][lane];
             if (narrow) {
-                p0 += red[1][0][r][lane] + red[2][0][r][lane];
-                p1 += red[1][1][r][lane] + red[2][1][r][lane];
-                p2 += red[1][2][r][lane] + red[2][2][r][lane];
+#pragma unroll
+                for (int w = 1; w < NW - 1; w++) { p0 += red[w][0][r][lane]; p1 += red[w][1][r][lane]; p2 += red[w][2][r][lane]; }
             }
             const float gh_r = acc0[r] + p0 + bh_r;
             const float gh_z = acc1[r] + p1 + bh_z;
@@ -613,8 +613,11 @@ __device__ __forceinline__ void gru_step_body(const GruStepArgs &a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) { gru_step_body(a); }
-__global__ __launch_bounds__(256) void k_gru_step_multi(GruStepMulti m) { gru_step_body(m.a[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_gru_step(GruStepArgs a) { gru_step_body<4>(a); }
+__global__ __launch_bounds__(256) void k_gru_step_multi(GruStepMulti m) { gru_step_body<4>(m.a[blockIdx.z]); }
+// batches of <= 16 streams: eight waves split K (4 k blocks each at H = 512: one round of loads in flight)
+__global__ __launch_bounds__(512) void k_gru_step8(GruStepArgs a) { gru_step_body<8>(a); }
+__global__ __launch_bounds__(512) void k_gru_step_multi8(GruStepMulti m) { gru_step_body<8>(m.a[blockIdx.z]); }
 
 // Second-generation step kernel: the workgroup's W_hh slice (3 gates x 16 hidden units x H, 96 KB at H = 512) is
 // staged ONCE through LDS in the exact lane order the B fragments are consumed (one conflict-free ds_read_b128 per

@@ -897,6 +897,7 @@ int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlappe
         const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : (overlapped || B <= 16);
         if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
         else if (H == 128 && !direct) hipLaunchKernelGGL(k_gru_step2<4>, grid, dim3(256), (size_t)192 * H, st, g);
+        else if (B <= 16) hipLaunchKernelGGL(k_gru_step8, grid, dim3(512), 0, st, g);
         else hipLaunchKernelGGL(k_gru_step, grid, dim3(256), 0, st, g);
         e->hcur[l] = hc ^ 1;
     }
@@ -941,7 +942,9 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
             e->hcur[l] = hc ^ 1;
         }
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H * z, st);
-        hipLaunchKernelGGL(k_gru_step_multi, dim3((H + 15) / 16, (B + 31) / 32, z), dim3(256), 0, st, m);
+        // (the same arithmetic as the single-stream path: batches of <= 16 streams split K over eight waves)
+        if (B <= 16) hipLaunchKernelGGL(k_gru_step_multi8, dim3((H + 15) / 16, 1, z), dim3(512), 0, st, m);
+        else hipLaunchKernelGGL(k_gru_step_multi, dim3((H + 15) / 16, (B + 31) / 32, z), dim3(256), 0, st, m);
     }
     HIPCHECK(e, hipGetLastError());
     return 0;

@@ -509,7 +509,8 @@ int se_train_gru_seq_fwd(const float *gi, const float *h0, const float *whh, con
     for (int t = 0; t < T; t++) {
         se::GruStepArgs g{gi + (size_t)t * 3 * H, (long)T * 3 * H, hb[t & 1], whh, bhh, hb[(t + 1) & 1], out + (size_t)t * H, (long)T * H, B, H,
                           gates + (size_t)t * 4 * H, (long)T * 4 * H};
-        hipLaunchKernelGGL(se::k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
+        if (B <= 16) hipLaunchKernelGGL(se::k_gru_step8, dim3((H + 15) / 16, 1), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL(se::k_gru_step, dim3((H + 15) / 16, (B + 31) / 32), dim3(256), 0, st, g);
     }
     if (hipMemcpyAsync(hT, hb[T & 1], (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return tfail(SE_ERR_HIP, "copy failed");
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gru sequence launch failed");
