@@ -187,7 +187,7 @@ int se_train_conv(int kind, const float *x, const float *xprev, const float *w_a
  * and of the transposed convolution (G = x, S = dy, Sprev = NULL) */
 int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, float *C, int B, int Ca, int Cb, int T, int Fm, int Fs, int dil,
                         void *stream);
-/* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU); bias may be NULL; K % 8 == 0 */
+/* C[M][N] = act(A[M][K] W[N][K]^T + bias[N])  (act: 0 none, 1 ReLU, 2 ELU); bias may be NULL; K % 8 == 0 */
 int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream);
 /* C[Na][Nb] = sum_r A[r][i] B[r][j], both operands row-major [R][.]: dense / 1x1-convolution weight gradients over R rows */
 int se_train_gemm_tn(const float *A, const float *B, float *C, int64_t R, int Na, int Nb, void *stream);

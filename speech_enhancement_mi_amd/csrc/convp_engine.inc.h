@@ -604,7 +604,9 @@ int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, lo
             const long nu = (long)Co * T * Fr;
             const uint4 *res = reinterpret_cast<const uint4 *>(S.xinP[lvl].p);
             const unsigned res_bytes = (unsigned)((size_t)S.slot_elems[lvl] * kRing * 16);
-            if (pv.sk.active) {
+            // one workgroup per stream: below ~100 streams most CUs would idle, the two k_conv_p launches (statistics, gate) spread
+            // over positions instead (B = 1: 24 vs 45 us per level).  SE_SKIP_STREAM=2 keeps the streaming kernel at any batch.
+            if (pv.sk.active && (B >= e->skip_min_batch || e->skip_stream == 2)) {
                 SkipPArgs a = pv.sk.a;
                 a.x = res + (long)cur * S.slot_elems[lvl];
                 a.ydec = S.decR[j].p;

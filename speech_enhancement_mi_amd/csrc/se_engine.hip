@@ -139,7 +139,13 @@ struct se_engine {
     int path = 1;
     bool use_p = false;
     // second-generation bottleneck GEMMs (k_gemm_p): A operands arrive as split-bf16 planes from their producers
-    bool gemm_p = false;      // decided in ensure_ready: plane path active, K dimensions multiples of 32 (SE_GEMM_P=0 disables)
+    bool gemm_p = false;      // decided in ensure_ready: plane path active, K dimensions multiples of 32 (SE_GEMM_P=0 disables);
+                              // off for batches of <= 64 GEMM rows (se_reset), which run on the skinny fp32 kernel instead
+    bool gemm_p_cap = false;
+    // measured crossovers (profiles: B = 16 / 32 / 64 / 128, 512-pt): the skinny kernel wins up to 640 GEMM rows (B = 32:
+    // 133 vs 228 us for the three GEMMs) and ties at 1280; the two-launch skip gate wins up to B = 64 (119 vs 147 us)
+    int skinny_rows = 800;    // SE_GEMM_SKINNY_ROWS: bottleneck GEMMs with up to this many rows run on the skinny fp32 kernel
+    int skip_min_batch = 96;  // SE_SKIP_MIN_BATCH: the streaming skip kernel needs at least this many streams
     int gemm_p_env = 1;
     DevBuf gruinP[kRing], seqP[4][kRing];  // [PL][B*T][D'] / [PL][B*T][H] bf16 planes
     DevBuf wih_xp;                          // W_ih0 planes with K in the engine's feature order (k_gemm_p)
@@ -702,6 +708,11 @@ int launch_conv(se_engine *e, const ConvPlan &pl, const float *x, const float *x
 
 int launch_gemm(se_engine *e, const float *A, long lda, const float *W, long ldw, const float *bias, float *C, long ldc,
                 int Mr, int Nc, int Kd, int relu, hipStream_t st, const char *label, const float *Wx = nullptr) {
+    if (Mr <= e->skinny_rows && lda == Kd && ldw == Kd && Kd % 8 == 0 && e->gemm_mode == 6) {  // few rows: 32 x 32 tiles, K split over the waves (fp32-exact MFMA)
+        ProfScope ps(e, "k_gemm_skinny", label, 2.0 * Mr * Nc * Kd, st);
+        if (se_train_gemm(A, W, bias, C, Mr, Nc, Kd, relu, st)) return fail(e, SE_ERR_HIP, "skinny GEMM launch failed: %s", se_train_last_error());
+        return 0;
+    }
     dim3 ggrid((Nc + kGemmBN - 1) / kGemmBN, (Mr + kGemmBM - 1) / kGemmBM);
     if (Wx && e->gemm_mode == 6 && Kd % 8 == 0 && Kd >= 8 && lda % 4 == 0 && ldw == Kd) {
         ProfScope ps(e, e->precision == 1 ? "k_gemm_f16" : (e->precision == 2 ? "k_gemm_bf16x3" : "k_gemm_bf16x6"), label, 2.0 * Mr * Nc * Kd, st);
@@ -1085,7 +1096,7 @@ int ensure_ready(se_engine *e) {
     if (replanned) {
         e->use_p = e->path != 0 && convp_supported(e);
         if (e->use_p && (rc = prepare_weights_p(e))) return rc;
-        e->gemm_p = e->use_p && e->gemm_p_env && !e->gru_seq && e->D % 32 == 0 && e->H % 32 == 0 && e->Ch[e->L] % 8 == 0;
+        e->gemm_p = e->gemm_p_cap = e->use_p && e->gemm_p_env && !e->gru_seq && e->D % 32 == 0 && e->H % 32 == 0 && e->Ch[e->L] % 8 == 0;
         if (e->gemm_p) {  // W_ih0 with its K axis in the engine's feature order k' = (o * F + f) * 8 + c  (reference d = (8 o + c) * F + f)
             const int Fl = e->F[e->L], D = e->D, H = e->H;
             const std::vector<float> &w = e->params["gru.sequence_model.weight_ih_l0"];
@@ -1169,6 +1180,8 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_DBG_SKIP")) e->dbg_skip = atoi(s);
     if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
     if (const char *s = getenv("SE_GEMM_P")) e->gemm_p_env = atoi(s);
+    if (const char *s = getenv("SE_GEMM_SKINNY_ROWS")) e->skinny_rows = atoi(s);
+    if (const char *s = getenv("SE_SKIP_MIN_BATCH")) e->skip_min_batch = atoi(s);
     e->cp = new se_convp_state();
     {
         int ncu = 0;
@@ -1286,6 +1299,9 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     if (rc) return rc;
     const int L = e->L, T = e->T, B = batch, H = e->H, D = e->D, F0 = e->F[0];
     e->B = B;
+    // a few streams give the bottleneck GEMMs a few hundred rows: a 256 x 128 tile per workgroup leaves 12-36 workgroups
+    // walking K = 2048 alone (124 us at B = 1); the skinny 32 x 32-tile fp32 kernel (K split over the waves) takes 24
+    e->gemm_p = e->gemm_p_cap && (long)B * T > e->skinny_rows;
     for (int i = 0; i < SE_MAX_LEVELS; i++)
         for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].skipm, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
             select_conv_geometry(e, *p);

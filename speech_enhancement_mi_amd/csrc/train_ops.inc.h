@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(SkinnyArgs a) {
                 if (m < a.M) {
                     float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + bs;
                     if (a.act == 1) v = fmaxf(v, 0.0f);
+                    else if (a.act == 2) v = v > 0.0f ? v : expf(v) - 1.0f;
                     a.C[(long)m * a.N + n] = v;
                 }
             }

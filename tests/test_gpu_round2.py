@@ -434,3 +434,23 @@ def test_reset_single_stream_student_plane_path(monkeypatch, pre_p):
         y_fresh = e_fresh.step(_cuda(w1)).cpu().numpy()
         assert rel_rms(y[1], y_fresh[0]) < 2e-6, k
         assert np.array_equal(y[0], y_cont[0]), k
+
+
+def test_small_batch_routes_match_large_batch_kernels(monkeypatch):
+    """Small batches route the bottleneck GEMMs to the skinny fp32 kernel and the skip gate to the two-launch k_conv_p form
+    (se_reset decides by batch); the large-batch kernels (k_gemm_p, k_skip_p) forced onto the same small batch must agree
+    to fp32 round-off, end to end and on the decoder taps."""
+    from test_gpu_parity import FULL512, _engine, _cuda, rel_rms
+    mix, _ = synth.synth_utterances(3, 9600, 3, seed=55)
+    x = _cuda(mix)
+    res = {}
+    for tag, rows, minb in (("small", "100000", "100000"), ("large", "0", "1")):
+        monkeypatch.setenv("SE_GEMM_SKINNY_ROWS", rows)
+        monkeypatch.setenv("SE_SKIP_MIN_BATCH", minb)
+        e = _engine(FULL512, seed=12)
+        y = e.realtime_process(x).cpu().numpy()
+        e.reset(3)
+        e.step(x[:, :, :3200].contiguous())
+        res[tag] = (y, np.asarray(e.read_tap("gru")), np.asarray(e.read_tap("dec0")), np.asarray(e.read_tap("dec2")))
+    for a, b in zip(res["small"], res["large"]):
+        assert a.shape == b.shape and rel_rms(a, b) < 2e-6
