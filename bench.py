@@ -308,12 +308,11 @@ def timed_region(fn, steps, warmup, world, backend):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
-def bench_train(args, rank, local_rank, world, backend):
+def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant=0, data="fixed"):
     """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
     all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
     micro-batches, grad accumulation 2 like config.yaml:99), all-reduce, clip, Adam.  value = utterances/s over all ranks."""
     import torch
-    import torch.distributed as dist
     from speech_enhancement_mi_amd import synth
     from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN, train_step
     cfg = crn_cfg(400)  # the reference's training geometry (config.yaml:205-217)
@@ -333,10 +332,10 @@ def bench_train(args, rank, local_rank, world, backend):
     def step():
         last["loss"] = train_step(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss)
 
-    progress(f"train: {args.warmup} + {args.steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
-    dt = timed_region(step, args.steps, args.warmup, world, backend)
+    progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
+    dt = timed_region(step, steps, warmup, world, backend)
     assert np.isfinite(last["loss"])
-    value = world * U * args.steps / dt
+    value = world * U * steps / dt
     roofline = None
     if args.train_kernels == "hip":  # one extra profiled step: events around every hand-written launch on the launch stream
         from speech_enhancement_mi_amd import train_ops
@@ -344,88 +343,121 @@ def bench_train(args, rank, local_rank, world, backend):
         step()
         prof = train_ops.profile_summary()
         train_ops.PROF = None
-        bwd = {k: v for k, v in prof.items() if k in ("k_corr_wgrad", "k_conv_igemm", "k_gemm_skinny")}
+        bwd = {k: v for k, v in prof.items() if v["flops"] > 0}
         dom = max(bwd, key=lambda k: bwd[k]["ms"])
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MATRIX_PEAK_TFLOPS,
+                        frac_of_executed_pipe=ach / FP32_MATRIX_PEAK_TFLOPS, executed_pipe="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                         traffic=None, avg_launch_us=1e3 * d["ms"] / d["launches"], launches_per_step=d["launches"],
                         note="dominant hand-written kernel of the training step (forward + backward); fp32-exact MFMA (v_mfma_f32_32x32x2_f32), "
                              "priced against the fp32 matrix peak; k_conv_igemm = conv / deconv forward AND their input gradients",
                         kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=v["flops"] / max(v["ms"], 1e-9) / 1e9) for k, v in prof.items()},
                         step_ms_profiled=sum(v["ms"] for v in prof.values()))
     result = dict(metric="DP training utterances/sec (TemporalCRN, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
-                  steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
+                  steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, higher_is_better=True, scaling="weak",
                   vs_baseline=None, dtype="f32", data="synthetic",
                   config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
-                                       f"loss = {args.train_loss}, flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
+                                       f"loss = {args.train_loss}, accum {args.accum}, flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
                               reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
                   roofline=roofline, cpu_baseline=None)
+    del model, bucket, opt, mix, clean
+    torch.cuda.empty_cache()
+    return result
+
+
+def train_line(args, rank, local_rank):
+    r = train_measure(args, rank, local_rank, 1, "none", steps=3, warmup=2)
+    return {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} | dict(workload=r["config"]["workload"])
+
+
+def bench_train(args, rank, local_rank, world, backend):
+    import torch.distributed as dist
+    result = train_measure(args, rank, local_rank, world, backend, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_fullsubnet(args, rank, local_rank, world, backend):
+def fullsubnet_measure(args, rank, local_rank, world, backend, B, dtype, steps, warmup):
     """BASELINE configs[2]: FullSubNet (fb + sb 2-layer LSTM) streaming inference, reference config.yaml:153-172."""
     import torch
-    import torch.distributed as dist
     from speech_enhancement_mi_amd import engine, synth
     spec = synth.fsn_param_spec(201, 3, 512, 384, 2, 15, 0)
-    eng = engine.FsnEngine(201, 3, 512, 384, 2, 15, 0, 0, 16000, 3200, 25, 10, 400, device=local_rank)
+    kw = {} if dtype == "f32" else dict(precision=PRECISIONS[dtype])
+    eng = engine.FsnEngine(201, 3, 512, 384, 2, 15, 0, 0, 16000, 3200, 25, 10, 400, device=local_rank, **kw)
     eng.load_state_dict(synth.make_state_dict(spec, seed=0))
-    B, L = args.batch, int(args.seconds * 16000)
+    L = int(args.seconds * 16000)
     base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)
     mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
     out = torch.empty((B, L), dtype=torch.float32, device="cuda")
     nseg = seg_count(L)
-    dt = timed_region(lambda: eng.realtime_process(mix, out=out), args.steps, args.warmup, world, backend)
+    progress(f"FullSubNet: {warmup} + {steps} steps, B={B}, {dtype}")
+    dt = timed_region(lambda: eng.realtime_process(mix, out=out), steps, warmup, world, backend)
     assert bool(torch.isfinite(out).all())
-    value = world * B * nseg * args.steps / dt
+    value = world * B * nseg * steps / dt
     tf = value / world * eng.flops_per_frame / 1e12
+    terms = {"f32": 6.0, "bf16x3": 3.0}[dtype]
     result = dict(metric=f"streaming frames/sec @ b{B} (FullSubNet, 3200-samp 16 kHz)", value=value, unit="frames/s", n_gpus=world,
-                  steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
-                  vs_baseline=None, dtype="f32", data="synthetic",
+                  steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, higher_is_better=True, scaling="weak",
+                  vs_baseline=None, dtype=dtype, data="synthetic",
                   config=dict(workload=f"FullSubNet realtime_process(train=False), batch {B} streams/GPU, 400-pt STFT / 201 bins, {args.seconds:g} s "
                                        f"utterances ({nseg} frames per stream), hash-generated weights", streams_per_gpu=B, frames_per_stream=nseg,
-                              realtime_factor=value * 0.1, audio_realtime_factor=world * B * args.seconds * args.steps / dt,
+                              realtime_factor=value * 0.1, audio_realtime_factor=world * B * args.seconds * steps / dt,
                               mflop_per_frame=eng.flops_per_frame / 1e6),
                   roofline=dict(bound="mfma", kernel="k_lstm_step_x6", achieved=tf, peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=tf / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
-                                note="whole-path rate; the fused sub-band LSTM step GEMM holds 99 % of the FLOPs (bf16x6 MFMA, see DESIGN.md)"),
+                                frac=tf / FP32_MATRIX_PEAK_TFLOPS, frac_of_executed_pipe=terms * tf / BF16_DENSE_PEAK_TFLOPS, terms_per_mac=terms,
+                                fp32_equivalent_roof=BF16_DENSE_PEAK_TFLOPS / terms, traffic=None,
+                                note="whole-path rate (algorithmic FLOPs of the whole frame / wall time); the fused sub-band LSTM step GEMM holds 99 % of "
+                                     "the FLOPs (split-bf16 MFMA, see DESIGN.md)"),
                   cpu_baseline=None)
+    eng.close()
+    del mix, out
+    torch.cuda.empty_cache()
+    return result
+
+
+def fullsubnet_line(args, rank, local_rank, B, dtype, steps, warmup):
+    r = fullsubnet_measure(args, rank, local_rank, 1, "none", B, dtype, steps, warmup)
+    return {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")}
+
+
+def bench_fullsubnet(args, rank, local_rank, world, backend):
+    import torch.distributed as dist
+    result = fullsubnet_measure(args, rank, local_rank, world, backend, args.batch, args.dtype, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_crn(args, rank, local_rank, world, backend):
+def measure_crn(model, nfft, B, dtype, seconds, steps, warmup, rank, local_rank, world, backend, label_progress=""):
+    """One CRN-family streaming workload: timed region + one extra profiled step (HIP events on the launch stream around every
+    launch).  Returns (value frames/s, ms_per_step, roofline dict, cfg, sd, variant, eng-derived info)."""
     import torch
-    import torch.distributed as dist
     from speech_enhancement_mi_amd import engine, synth
-    cfg = crn_cfg(args.nfft, args.model)
-    variant, _, _, label = MODELS[args.model]
+    cfg = crn_cfg(nfft, model)
+    variant, _, _, label = MODELS[model]
     spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=variant)
     sd = synth.make_state_dict(spec, seed=0)
-    eng = engine.Engine(engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], 3200, 2, 3, 3, 16000, 25, 10, args.nfft,
-                                           variant=variant, precision=PRECISIONS[args.dtype]), local_rank)
+    eng = engine.Engine(engine.make_config(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], 3200, 2, 3, 3, 16000, 25, 10, nfft,
+                                           variant=variant, precision=PRECISIONS[dtype]), local_rank)
     eng.load_state_dict(sd)
 
-    B, L = args.batch, int(args.seconds * 16000)
+    L = int(seconds * 16000)
     base, _ = synth.synth_utterances(min(B, 16), L, 3, seed=1000 + rank)  # 16 distinct utterances, tiled over the batch
     mix = torch.from_numpy(np.ascontiguousarray(np.tile(base, (-(-B // base.shape[0]), 1, 1))[:B])).cuda()
     out = torch.empty((B, L), dtype=torch.float32, device="cuda")
     nseg = seg_count(L)
 
-    progress(f"timed region: {args.warmup} + {args.steps} steps")
-    dt = timed_region(lambda: eng.realtime_process(mix, out=out), args.steps, args.warmup, world, backend)
+    progress(f"{label_progress}timed region: {warmup} + {steps} steps ({model}, B={B}, {nfft}-pt, {dtype})")
+    dt = timed_region(lambda: eng.realtime_process(mix, out=out), steps, warmup, world, backend)
     assert bool(torch.isfinite(out).all()), "non-finite output"
-    progress(f"{world * B * nseg * args.steps / dt:.0f} frames/s; profiled step")
-    frames = world * B * nseg * args.steps
+    frames = world * B * nseg * steps
     value = frames / dt
+    progress(f"{label_progress}{value:.0f} frames/s; profiled step")
 
     # ---- roofline leg: one extra profiled step, HIP events around every launch on the launch stream ----
     eng.profile(True)
@@ -442,39 +474,99 @@ def bench_crn(args, rank, local_rank, world, backend):
     d = by_kernel[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     # The contraction kernels produce fp32-accurate results from split-bf16 MFMAs (6 products per MAC at precision f32, 3 at
-    # bf16x3): `achieved` counts ALGORITHMIC fp32 FLOPs and is priced against the fp32 matrix peak, the peak of
-    # the dtype the path computes in; the bf16 matrix-core work actually executed is reported next to the bf16 dense peak.
-    terms = {"f32": 6.0, "bf16x3": 3.0, "f16": 1.0}[args.dtype]
-    split = args.dtype in ("f32", "bf16x3")
+    # bf16x3).  `achieved` counts ALGORITHMIC fp32 FLOPs.  Two prices are reported: `frac` against the fp32 matrix
+    # peak (the peak of the dtype the path's RESULTS are in - the number the previous rounds quoted), and
+    # `frac_of_executed_pipe` = executed bf16/fp16 MFMA FLOPs / the dense bf16 peak of the pipe the kernel actually runs on
+    # (equivalently achieved / (2.5 PF / terms)): a kernel can exceed the former, never the latter.
+    terms = {"f32": 6.0, "bf16x3": 3.0, "f16": 1.0}[dtype]
+    split = dtype in ("f32", "bf16x3")
     peak = FP32_MATRIX_PEAK_TFLOPS if split else BF16_DENSE_PEAK_TFLOPS  # fp16 operands: priced against the dense fp16 matrix peak
-    workload_key = f"{args.model}/b{B}/nfft{args.nfft}/{args.dtype}"
+    workload_key = f"{model}/b{B}/nfft{nfft}/{dtype}"
     traffic, traffic_note = pmc_traffic(dom, workload_key)
+    pipe_peak_equiv = BF16_DENSE_PEAK_TFLOPS / terms
     roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s",
-                    frac=achieved / peak, traffic=traffic, traffic_note=traffic_note,
+                    frac=achieved / peak, frac_of_executed_pipe=terms * achieved / BF16_DENSE_PEAK_TFLOPS,
+                    executed_pipe="bf16 MFMA (v_mfma_f32_32x32x16_bf16)" if split else "fp16 MFMA",
+                    executed_pipe_peak=BF16_DENSE_PEAK_TFLOPS, terms_per_mac=terms, fp32_equivalent_roof=pipe_peak_equiv,
+                    traffic=traffic, traffic_note=traffic_note,
                     executed_bf16_tflops=(terms * achieved if split else None), bf16_dense_peak=(BF16_DENSE_PEAK_TFLOPS if split else None),
                     avg_launch_us=1e3 * d["ms"] / max(1, d["launches"]), launches_per_step=d["launches"],
                     flops_per_launch=d["flops"] / max(1, d["launches"]),
                     whole_path_tflops=value / world * eng.flops_per_frame / 1e12,
                     kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
-                                     tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0))
+                                     tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                                     frac_of_executed_pipe=(terms * v["flops"] / (v["ms"] * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS if v["ms"] > 0 else 0.0))
                              for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])},
                     labels={r["label"]: dict(ms=round(r["ms"], 3), launches=r["launches"]) for r in recs})
+    info = dict(cfg=cfg, sd=sd, variant=variant, label=label, nseg=nseg, mflop_per_frame=eng.flops_per_frame / 1e6, dt=dt)
+    eng.close()
+    del mix, out
+    torch.cuda.empty_cache()
+    return value, 1e3 * dt / steps, roofline, info
 
-    tol_note = {"f32": "fp32-accurate (6-term split-bf16 MFMA), parity <= 1e-6 rel vs reference",
-                "bf16x3": "3-term split-bf16 MFMA (hi*hi + hi*mid + mid*hi), parity checked against the reference goldens at 1e-4 rel RMS / 0.02 dB",
-                "f16": "fp16 MFMA operands, fp32 accumulate: OUTSIDE north_star's 1e-4 / 0.02 dB parity bar (1.6e-3..2.6e-3 rel, <= 0.05 dB), reported for reference only"}[args.dtype]
+
+TOL_NOTE = {"f32": "fp32-accurate (6-term split-bf16 MFMA), parity <= 1e-6 rel vs reference",
+            "bf16x3": "3-term split-bf16 MFMA (hi*hi + hi*mid + mid*hi), parity checked against the reference goldens at 1e-4 rel RMS / 0.02 dB",
+            "f16": "fp16 MFMA operands, fp32 accumulate: OUTSIDE north_star's 1e-4 / 0.02 dB parity bar (1.6e-3..2.6e-3 rel, <= 0.05 dB), reported for reference only"}
+
+
+def secondary_lines(args, rank, local_rank):
+    """BASELINE configs 3, 4, 5 (+ CRN_ELU) under the same clock as the headline, a few steps each, AFTER the headline's timed
+    region (N = 1 only).  Each entry: {config, metric, value, unit, ms_per_step, steps, roofline{kernel, achieved, frac (vs the fp32
+    matrix peak), frac_of_executed_pipe (vs 2.5 PF / terms)}}.  A failing leg is recorded as {"error": ...}: it never takes the
+    headline line down."""
+    out = []
+
+    def leg(name, fn):
+        t0 = time.time()
+        try:
+            r = fn()
+        except Exception as ex:  # noqa: BLE001 - a secondary leg must not lose the headline
+            r = dict(error=f"{type(ex).__name__}: {ex}"[:400])
+        r["config"] = name
+        r["wall_s"] = round(time.time() - t0, 2)
+        out.append(r)
+
+    def crn_leg(model, B, dtype, nfft, steps=3, warmup=1):
+        def fn():
+            value, ms, roof, info = measure_crn(model, nfft, B, dtype, args.seconds, steps, warmup, rank, local_rank, 1, "none", label_progress="secondary: ")
+            slim = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_executed_pipe", "terms_per_mac",
+                                         "fp32_equivalent_roof", "avg_launch_us", "launches_per_step", "whole_path_tflops")}
+            slim["traffic"] = roof["traffic"]
+            slim["kernels"] = {k: v for k, v in list(roof["kernels"].items())[:6]}
+            return dict(metric=f"streaming frames/sec @ b{B} ({info['label']}, 3200-samp 16 kHz)", value=value, unit="frames/s", ms_per_step=ms,
+                        steps=steps, warmup=warmup, dtype=dtype, n_fft=nfft, mflop_per_frame=info["mflop_per_frame"], precision=TOL_NOTE[dtype], roofline=slim)
+        return fn
+
+    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, f32", lambda: fullsubnet_line(args, rank, local_rank, 256, "f32", steps=2, warmup=1))
+    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, bf16x3", lambda: fullsubnet_line(args, rank, local_rank, 256, "bf16x3", steps=2, warmup=1))
+    leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, bf16x3 (inside the parity bar)", crn_leg("student", 1024, "bf16x3", 400))
+    leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, f16 (the config's named dtype; outside the parity bar)", crn_leg("student", 1024, "f16", 400))
+    leg("CRN_ELU (the variant train.py trains) streaming, batch 256, f32", crn_leg("crn_elu", 256, "f32", 400))
+    leg("BASELINE configs[3]: TemporalCRN training step, 8 x 3 s utterances per GPU, accum 2, full loss", lambda: train_line(args, rank, local_rank))
+    return out
+
+
+def bench_crn(args, rank, local_rank, world, backend):
+    import torch.distributed as dist
+    B = args.batch
+    value, ms_per_step, roofline, info = measure_crn(args.model, args.nfft, B, args.dtype, args.seconds, args.steps, args.warmup, rank, local_rank, world, backend)
+    cfg, sd, variant, label, nseg = info["cfg"], info["sd"], info["variant"], info["label"], info["nseg"]
+    dt = info["dt"]
     result = dict(metric=f"streaming frames/sec @ b{B} ({label}, 3200-samp 16 kHz)", value=value, unit="frames/s",
-                  n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+                  n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                   config=dict(workload=f"TemporalCRN ({args.model}) realtime_process, batch {B} streams/GPU, {args.nfft}-pt STFT / {cfg['num_freqs']} bins, hop 160, "
                                        f"{args.seconds:g} s utterances ({nseg} frames of 3200 samples per stream), hash-generated weights",
                               streams_per_gpu=B, frames_per_stream=nseg, n_fft=args.nfft, parallelism=f"streams sharded x{world}, no collective",
                               realtime_factor=value * 0.1,  # SURVEY 8d definition: every frame (incl. the reference's pad / gap frames) = 100 ms
                               audio_realtime_factor=world * B * args.seconds * args.steps / dt,  # real seconds of audio / wall second
-                              mflop_per_frame=eng.flops_per_frame / 1e6, precision=tol_note, collective_backend=backend),
+                              mflop_per_frame=info["mflop_per_frame"], precision=TOL_NOTE[args.dtype], collective_backend=backend),
                   roofline=roofline)
     if rank == 0:
         result["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary:
+            result["secondary"] = secondary_lines(args, rank, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu_baseline: C oracle")
             result["cpu_baseline"] = cpu_baseline(cfg, sd, variant)
@@ -503,6 +595,7 @@ def parse_args(argv=None):
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dtype", choices=sorted(PRECISIONS), default="f32",
                     help="f32 = fp32-accurate contractions (headline); bf16x3 = 3-term split-bf16 (inside the 1e-4 parity bar; BASELINE config 5: "

@@ -1087,6 +1087,10 @@ int launch_istft(se_engine *e, const cf2 *spec, long sR, long sT, long sF, int r
     return 0;
 }
 
+// The one place that decides the bottleneck GEMM route of the current batch: plane GEMMs (k_gemm_p) when the engine can run
+// them AND the batch has more rows than the skinny fp32 kernel wins at.  Called after every re-plan and from se_reset.
+void select_gemm_route(se_engine *e) { e->gemm_p = e->gemm_p_cap && e->B > 0 && (long)e->B * e->T > e->skinny_rows; }
+
 int ensure_ready(se_engine *e) {
     if (!e) return SE_ERR_ARG;
     HIPCHECK(e, hipSetDevice(e->device));
@@ -1096,8 +1100,11 @@ int ensure_ready(se_engine *e) {
     if (replanned) {
         e->use_p = e->path != 0 && convp_supported(e);
         if (e->use_p && (rc = prepare_weights_p(e))) return rc;
-        e->gemm_p = e->gemm_p_cap = e->use_p && e->gemm_p_env && !e->gru_seq && e->D % 32 == 0 && e->H % 32 == 0 && e->Ch[e->L] % 8 == 0;
-        if (e->gemm_p) {  // W_ih0 with its K axis in the engine's feature order k' = (o * F + f) * 8 + c  (reference d = (8 o + c) * F + f)
+        // capability only: whether THIS batch takes the plane GEMMs is select_gemm_route()'s decision (a batch on the skinny route
+        // never allocated gruinP / seqP, so a weight reload must not switch the plane route back on behind its back)
+        e->gemm_p_cap = e->use_p && e->gemm_p_env && !e->gru_seq && e->D % 32 == 0 && e->H % 32 == 0 && e->Ch[e->L] % 8 == 0;
+        select_gemm_route(e);
+        if (e->gemm_p_cap) {  // W_ih0 with its K axis in the engine's feature order k' = (o * F + f) * 8 + c  (reference d = (8 o + c) * F + f)
             const int Fl = e->F[e->L], D = e->D, H = e->H;
             const std::vector<float> &w = e->params["gru.sequence_model.weight_ih_l0"];
             std::vector<float> wp((size_t)3 * H * D);
@@ -1177,7 +1184,11 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_DEC_MERGE")) e->dec_merge = atoi(s);
     if (const char *s = getenv("SE_PATH")) e->path = atoi(s);
     if (const char *s = getenv("SE_SKIP_STREAM")) e->skip_stream = atoi(s);
-    if (const char *s = getenv("SE_DBG_SKIP")) e->dbg_skip = atoi(s);
+#ifdef SE_DEBUG_KNOBS  // timing-experiment build only (profiles/pipe_split.sh): drops whole stages, the audio is WRONG
+    if (const char *s = getenv("SE_DBG_SKIP")) { e->dbg_skip = atoi(s); fprintf(stderr, "se_engine: SE_DBG_SKIP=%d - stages are skipped, results are WRONG (timing experiment)\n", e->dbg_skip); }
+#else
+    if (getenv("SE_DBG_SKIP")) return bail(SE_ERR_ARG, "SE_DBG_SKIP is set but this library was built without -DSE_DEBUG_KNOBS: refusing to run (the knob drops whole stages and produces wrong audio)");
+#endif
     if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
     if (const char *s = getenv("SE_GEMM_P")) e->gemm_p_env = atoi(s);
     if (const char *s = getenv("SE_GEMM_SKINNY_ROWS")) e->skinny_rows = atoi(s);
@@ -1301,7 +1312,7 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     e->B = B;
     // a few streams give the bottleneck GEMMs a few hundred rows: a 256 x 128 tile per workgroup leaves 12-36 workgroups
     // walking K = 2048 alone (124 us at B = 1); the skinny 32 x 32-tile fp32 kernel (K split over the waves) takes 24
-    e->gemm_p = e->gemm_p_cap && (long)B * T > e->skinny_rows;
+    select_gemm_route(e);
     for (int i = 0; i < SE_MAX_LEVELS; i++)
         for (ConvPlan *p : {&e->lv[i].enc, &e->lv[i].dec_even, &e->lv[i].dec_odd, &e->lv[i].skip, &e->lv[i].skipm, &e->lv[i].gate[0], &e->lv[i].gate[1], &e->lv[i].pre})
             select_conv_geometry(e, *p);

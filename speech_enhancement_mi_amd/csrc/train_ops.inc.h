@@ -12,19 +12,10 @@
 // Everything is fp32 with exact MFMA accumulation order (v_mfma_f32_32x32x2_f32 / 16x16x4), so gradients agree with torch
 // autograd to rounding; the checker is tests/test_gpu_round2.py::test_hip_training_ops_vs_autograd.
 
+namespace se { int train_fail(int code, const char *fmt, ...); }  // se_train.hip (owns se_train_last_error)
+#define tfail se::train_fail
+
 namespace {
-
-thread_local std::string g_train_error;
-
-int tfail(int code, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_train_error = buf;
-    return code;
-}
 
 struct TrainConvGeo {
     ConvArgs a{};
@@ -417,8 +408,6 @@ __global__ __launch_bounds__(kGruBwdWaves * 64) void k_gru_bwd_step(GruBwdStepAr
 }  // namespace se
 
 extern "C" {
-
-const char *se_train_last_error(void) { return g_train_error.c_str(); }
 
 int se_train_conv_layout_query(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil, se_train_conv_layout *out) {
     if (!out) return tfail(SE_ERR_ARG, "null argument");

@@ -23,7 +23,7 @@ EXPORTS = [
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
     "se_train_last_error", "se_train_conv_layout_query", "se_train_conv", "se_train_conv_wgrad", "se_train_gemm", "se_train_gemm_tn", "se_train_gru_step",
-    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_synth_last_error", "se_synth_rir", "se_synth_fir", "se_synth_mix",
+    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd", "se_synth_last_error", "se_synth_rir", "se_synth_fir", "se_synth_mix",
 ]
 
 
@@ -108,6 +108,9 @@ def load_library():
     L.se_train_gru_bwd_gates.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, vp]
     L.se_train_gru_seq_fwd.argtypes = [vp] * 8 + [i32, i32, i32, vp]
     L.se_train_gru_seq_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, vp]
+    L.se_train_gru_pseq_supported.argtypes = [i32, i32]
+    L.se_train_gru_pseq_fwd.argtypes = [vp] * 8 + [i32, i32, i32, i32, i64, i64, vp]
+    L.se_train_gru_pseq_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, i64, i64, i32, vp]
     L.se_synth_last_error.restype = C.c_char_p
     L.se_synth_rir.argtypes = [vp, vp, vp, vp] + [i32] * 6 + [C.c_float, C.c_float, i32, vp, vp]
     L.se_synth_fir.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp, vp]

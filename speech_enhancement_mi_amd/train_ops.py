@@ -224,16 +224,88 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+_pseq_scratch = {}
+
+
+def _scratch(dev, B, H):
+    """Exchange buffer + arrival / timeout words of the persistent GRU launches (stream-ordered reuse)."""
+    key = (dev.index, B, H)
+    t = _pseq_scratch.get(key)
+    if t is None:
+        t = _pseq_scratch[key] = torch.zeros(16 + 6 * B * H, device=dev, dtype=torch.float32)
+    return t
+
+
+def pseq_check():
+    """Raises if any persistent GRU launch since the last check gave up its bounded spin (one host sync; train_step calls it
+    where it reads the loss value anyway)."""
+    for key, t in _pseq_scratch.items():
+        if int(t[:4].view(torch.int32)[1]) != 0:
+            t[:4].zero_()
+            raise RuntimeError(f"persistent GRU kernel timed out waiting for its peer workgroups (device {key[0]}, B = {key[1]}, H = {key[2]})")
+
+
+def _gru_seq_fwd(gi, h0, w_hh, b_hh, out, gates, hT, B, T, H, Tseg, ldN, ldB):
+    """All T steps of one layer.  gi / out / gates rows are addressed as row(b, s) = (s // Tseg) * ldN + b * ldB + s % Tseg."""
+    lib = _lib()
+    if lib.se_train_gru_pseq_supported(min(B, 32), H):
+        for b0 in range(0, B, 32):  # one persistent launch per group of <= 32 streams
+            nb = min(32, B - b0)
+            sc = _scratch(gi.device, nb, H)
+            off = b0 * ldB
+            with _Timed("k_gru_pseq_fwd", 2.0 * nb * 3 * H * H * T):
+                _chk(lib.se_train_gru_pseq_fwd(C.c_void_p(gi.data_ptr() + 4 * off * 3 * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh), _p(b_hh),
+                                               C.c_void_p(out.data_ptr() + 4 * off * H), C.c_void_p(gates.data_ptr() + 4 * off * 4 * H),
+                                               C.c_void_p(hT.data_ptr() + 4 * b0 * H), _p(sc), nb, T, H, Tseg, ldN, ldB, _st()))
+        return
+    if Tseg != T or ldB != T:
+        raise RuntimeError(f"hidden size {H}: no persistent GRU kernel, and the step-launch kernels take [B][T] rows only")
+    for b0 in range(0, B, 16):  # step-launch kernels (round 2): groups of <= 16 streams
+        nb = min(16, B - b0)
+        scratch = torch.empty(2, nb, H, device=gi.device, dtype=torch.float32)
+        with _Timed("k_gru_step", 2.0 * nb * 3 * H * H * T):
+            _chk(lib.se_train_gru_seq_fwd(C.c_void_p(gi.data_ptr() + 4 * b0 * T * 3 * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh), _p(b_hh),
+                                          C.c_void_p(out.data_ptr() + 4 * b0 * T * H), C.c_void_p(gates.data_ptr() + 4 * b0 * T * 4 * H),
+                                          C.c_void_p(hT.data_ptr() + 4 * b0 * H), _p(scratch), nb, T, H, _st()))
+
+
+def _gru_seq_bwd(dout, dhT, gates, out, h0, w_hh_t, dgi, dgh, B, T, H, Tseg, ldN, ldB, seg_len):
+    lib = _lib()
+    if lib.se_train_gru_pseq_supported(min(B, 32), H):
+        for b0 in range(0, B, 32):
+            nb = min(32, B - b0)
+            sc = _scratch(dout.device, nb, H)
+            off = b0 * ldB
+            dh = None if dhT is None else C.c_void_p(dhT.data_ptr() + 4 * b0 * H)
+            with _Timed("k_gru_pseq_bwd", 2.0 * nb * 3 * H * H * T):
+                _chk(lib.se_train_gru_pseq_bwd(C.c_void_p(dout.data_ptr() + 4 * off * H), dh, C.c_void_p(gates.data_ptr() + 4 * off * 4 * H),
+                                               C.c_void_p(out.data_ptr() + 4 * off * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh_t),
+                                               C.c_void_p(dgi.data_ptr() + 4 * off * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * off * 3 * H), _p(sc),
+                                               nb, T, H, Tseg, ldN, ldB, seg_len, _st()))
+        return
+    if Tseg != T or ldB != T:
+        raise RuntimeError(f"hidden size {H}: no persistent GRU kernel, and the step-launch kernels take [B][T] rows only")
+    for b0 in range(0, B, 16):
+        nb = min(16, B - b0)
+        scratch = torch.empty(4, nb, H, device=out.device, dtype=torch.float32)
+        dh = None if dhT is None else C.c_void_p(dhT.data_ptr() + 4 * b0 * H)
+        with _Timed("k_gru_bwd_step", 2.0 * nb * 3 * H * H * T):
+            _chk(lib.se_train_gru_seq_bwd(C.c_void_p(dout.data_ptr() + 4 * b0 * T * H), dh, C.c_void_p(gates.data_ptr() + 4 * b0 * T * 4 * H),
+                                          C.c_void_p(out.data_ptr() + 4 * b0 * T * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh_t),
+                                          C.c_void_p(dgi.data_ptr() + 4 * b0 * T * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * b0 * T * 3 * H), _p(scratch),
+                                          nb, T, H, seg_len, _st()))
+
+
 class _GruLayerFn(torch.autograd.Function):
     """One GRU layer, batch_first: x [B, T, In], h0 [B, H] (a constant: the carried state is detached, CRN.py:281) ->
     (out [B, T, H], hT [B, H]).  seg_len > 0: the sequence is a chain of segments of seg_len steps whose carried state is
     detached at every seam, so the backward sweep drops the gradient that would cross a seam (truncated BPTT exactly as the
-    per-segment loop of CRN.py:577-586 does it).  The time loops run inside the library (se_train_gru_seq_fwd / _bwd)."""
+    per-segment loop of CRN.py:577-586 does it).  The time loop runs inside ONE persistent launch per direction
+    (se_train_gru_pseq_*, csrc/gru_pseq.hip.h); hidden sizes that kernel does not cover fall back to one launch per step."""
 
     @staticmethod
     def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, seg_len):
         _need_gpu(x, w_ih)
-        lib = _lib()
         B, T, In = x.shape
         H = w_hh.shape[1]
         x2 = x.reshape(B * T, In).contiguous()
@@ -241,10 +313,8 @@ class _GruLayerFn(torch.autograd.Function):
         out = torch.empty(B, T, H, device=x.device, dtype=torch.float32)
         gates = torch.empty(B, T, 4 * H, device=x.device, dtype=torch.float32)
         hT = torch.empty(B, H, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(2, B, H, device=x.device, dtype=torch.float32)
         h0c, w_hh_c, b_hh_c = h0.contiguous(), w_hh.contiguous(), b_hh.contiguous()
-        with _Timed("k_gru_step", 2.0 * B * 3 * H * H * T):
-            _chk(lib.se_train_gru_seq_fwd(_p(gi), _p(h0c), _p(w_hh_c), _p(b_hh_c), _p(out), _p(gates), _p(hT), _p(scratch), B, T, H, _st()))
+        _gru_seq_fwd(gi, h0c, w_hh_c, b_hh_c, out, gates, hT, B, T, H, T, 0, T)
         ctx.save_for_backward(x2, h0c, w_ih, w_hh_c, out, gates)
         ctx.dims = (B, T, In, H, int(seg_len))
         return out, hT
@@ -252,34 +322,12 @@ class _GruLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dhT):
         x2, h0, w_ih, w_hh, out, gates = ctx.saved_tensors
-        lib = _lib()
         B, T, In, H, seg_len = ctx.dims
         dout = dout.contiguous()
         dgi = torch.empty(B, T, 3 * H, device=out.device, dtype=torch.float32)
         dgh = torch.empty(B, T, 3 * H, device=out.device, dtype=torch.float32)
         w_hh_t = w_hh.t().contiguous()  # [H, 3H]: dh_{t-1} += dgh W_hh with K-contiguous operands
-        if B <= 16:
-            scratch = torch.empty(4, B, H, device=out.device, dtype=torch.float32)
-            dhT_c = dhT.contiguous() if dhT is not None else None
-            with _Timed("k_gru_bwd_step", 2.0 * B * 3 * H * H * T):
-                _chk(lib.se_train_gru_seq_bwd(_p(dout), _p(dhT_c), _p(gates), _p(out), _p(h0), _p(w_hh_t), _p(dgi), _p(dgh), _p(scratch), B, T, H,
-                                              seg_len, _st()))
-        else:  # wide batches: gate kernel + GEMM per step
-            dhz = torch.empty(B, H, device=out.device, dtype=torch.float32)
-            st = _st()
-            carry_z, carry_g = (dhT.contiguous() if dhT is not None else None), None
-            for t in range(T - 1, -1, -1):
-                hp_ptr = C.c_void_p(h0.data_ptr()) if t == 0 else C.c_void_p(out.data_ptr() + 4 * (t - 1) * H)
-                hp_ld = H if t == 0 else T * H
-                _chk(lib.se_train_gru_bwd_gates(C.c_void_p(dout.data_ptr() + 4 * t * H), T * H, _p(carry_z), _p(carry_g),
-                                                C.c_void_p(gates.data_ptr() + 4 * t * 4 * H), T * 4 * H, hp_ptr, hp_ld,
-                                                C.c_void_p(dgi.data_ptr() + 4 * t * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * t * 3 * H), T * 3 * H,
-                                                _p(dhz), B, H, st))
-                if t > 0 and seg_len > 0 and t % seg_len == 0:
-                    carry_z, carry_g = None, None  # segment seam: the state entering step t was detached
-                else:
-                    carry_z = dhz.clone()
-                    carry_g = _gemm(dgh[:, t].contiguous(), w_hh_t) if t > 0 else None
+        _gru_seq_bwd(dout, dhT.contiguous() if dhT is not None else None, gates, out, h0, w_hh_t, dgi, dgh, B, T, H, T, 0, T, seg_len)
         dgi2, dgh2 = dgi.reshape(B * T, 3 * H), dgh.reshape(B * T, 3 * H)
         hprev_all = torch.cat([h0[:, None], out[:, :-1]], dim=1).reshape(B * T, H)
         dx = _gemm(dgi2, w_ih.t().contiguous()).reshape(B, T, In) if ctx.needs_input_grad[0] else None

@@ -316,6 +316,9 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
             val = si_snr_loss(pred, src, ln) / accum
         val.backward()
         total += float(val.detach())
+    if model._hip:
+        from . import train_ops
+        train_ops.pseq_check()  # a persistent GRU launch that gave up its bounded spin must not go unnoticed
     bucket.all_reduce_mean()
     bucket.clip_(5.0)
     optimizer.step()
