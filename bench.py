@@ -330,7 +330,7 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant
     last = {}
 
     def step():
-        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss)
+        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss, merge=not args.no_merge)
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
@@ -358,7 +358,8 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant
                   steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, higher_is_better=True, scaling="weak",
                   vs_baseline=None, dtype="f32", data="synthetic",
                   config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
-                                       f"loss = {args.train_loss}, accum {args.accum}, flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
+                                       f"loss = {args.train_loss}, accum {args.accum} ({'micro-batches share one forward/backward sweep, loss formed per micro-batch: same gradient' if not args.no_merge else 'micro-batches run one after the other'}), "
+                                       f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
                               reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
                   roofline=roofline, cpu_baseline=None)
@@ -594,6 +595,7 @@ def parse_args(argv=None):
     ap.add_argument("--train-loss", choices=["full", "sisnr"], default="full",
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
+    ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)

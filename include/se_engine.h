@@ -124,7 +124,7 @@ int se_profile(se_engine *e, int enable);
 int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap, double *ms_total,
                     int64_t *launches, double *flops_per_launch);
 
-int se_abi_version(void);
+int se_abi_version(void);  /* 4 since round 3 (fsn_config.precision, se_sig_*, fused training stages) */
 /* sizeof(se_config) / sizeof(fsn_config) as this library was built: a binding checks its own struct mirror against these
  * before the first se_create (a short struct would leave `precision` reading whatever follows it). */
 int se_config_size(void);
@@ -218,6 +218,63 @@ int se_train_gru_pseq_fwd(const float *gi, const float *h0, const float *whh, co
 int se_train_gru_pseq_bwd(const float *dout, const float *dhT, const float *gates, const float *out, const float *h0, const float *whh_t,
                           float *dgi, float *dgh, float *scratch, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, int seg_len,
                           void *stream);
+
+/* ---- round 3: the norm / pointwise / signal stages of the training step, forward and backward (csrc/train_fused.hip.h) ----
+ * Layout: activations [S][C][T][F] fp32, S = N segments x B utterances, SEGMENT-major (stream n * B + b), so the time history of
+ * segment n is the same tensor one slab (B streams) earlier and the per-segment loop of realtime_process (CRN.py:577-586) becomes one
+ * launch per layer.  All gradients of per-channel parameters are produced as [S][C] slabs and folded by se_train_colsum: the
+ * training step contains no float atomics (bit-reproducible gradients). */
+typedef struct se_sig se_sig;   /* STFT tables: hamming(win) centred in n_fft, twiddles, overlap-add envelope */
+int se_sig_create(int n_fft, int win, int hop, int segment_length, int device, se_sig **out);
+void se_sig_destroy(se_sig *g);
+/* stft_trans of ALL segments (CRN.py:505-512 + utility.padding / segmentation, utility.py:312-370): wav [B][M][L]; segment y of row
+ * (b, m) covers samples off0 + y * seg_off + [0, K) (zero outside [0, L)) -> spec [nseg][B*M][T][F][2] */
+int se_sig_stft(se_sig *g, const float *wav, int B, int M, int64_t L, int64_t off0, int64_t seg_off, int nseg, float *spec, void *stream);
+/* istft_trans (CRN.py:514-520): spec [rows][T][F][2] -> wav [rows][K].  Its adjoint is se_sig_stft of (dy / envelope) followed by the
+ * irfft weights, which se_train_ola_bwd and se_train_mask_bwd apply. */
+int se_sig_istft(se_sig *g, const float *spec, int rows, float *wav, void *stream);
+/* utility.over_add + the K/2 strip (utility.py:373-403, CRN.py:587-588) on segment-major yseg [nseg][B][K] -> out [B][L]; skip = K/2
+ * when realtime_process padded the input (flag=False), else 0.  bwd: gseg [nseg][B][K] = adjoint(dout) / envelope. */
+int se_train_ola_fwd(se_sig *g, const float *yseg, float *out, int B, int64_t L, int64_t skip, void *stream);
+int se_train_ola_bwd(se_sig *g, const float *dout, float *gseg, int B, int nseg, int64_t L, int64_t skip, void *stream);
+/* features (CRN.py:463-467): spec [S][M][T][F][2] -> feat [S][2M-1][T][F] (no backward: the input carries no gradient) */
+int se_train_feat(const float *spec, float *feat, int S, int M, int T, int F, int atan2_phase, void *stream);
+/* decompress_cIRM + complex multiply with microphone 0 (utility.py:439-442, CRN.py:491-495): x [S][2][T][F] -> Y [S][T][F][2];
+ * bwd takes dY = se_sig_stft(gseg) (raw) and returns dx */
+int se_train_mask_fwd(const float *x, const float *spec, float *Y, int S, int M, int T, int F, void *stream);
+int se_train_mask_bwd(const float *dY, const float *x, const float *spec, float *dx, int S, int M, int T, int F, int n_fft, void *stream);
+/* y = GlobalLayerNorm(act(x)) (CRN.py:135-149) per stream; element (s, c, t, f) of x at s*xS + c*xC + t*xT + f (same form for y, dy);
+ * mode 0: affine per channel, mode 1: per feature c*Fi + f (last=True); act 0 none / 1 ReLU / 2 ELU; Fo >= Fi zero-fills the
+ * decoder's frequency pad (CRN.py:389-392); stats [S][2] = mean, 1/(sqrt(var+eps)+eps).
+ * bwd: dx (x strides) = gradient w.r.t. the PRE-activation x; dw_part / db_part / dpre_part [S][NA] slabs (NA = C or C*Fi; any may be
+ * NULL), dpre = per-channel sum of dx = the producing convolution's bias gradient. */
+int se_train_gln_fwd(const float *x, int64_t xS, int64_t xC, int64_t xT, float *y, int64_t yS, int64_t yC, int64_t yT, const float *w, const float *b,
+                     float *stats, int S, int C, int T, int Fi, int Fo, int mode, int act, int eps_mode, void *stream);
+int se_train_gln_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const float *x, int64_t xS, int64_t xC, int64_t xT, float *dx, const float *w,
+                     const float *stats, float *dw_part, float *db_part, float *dpre_part, int S, int C, int T, int Fi, int mode, int act,
+                     int eps_mode, void *stream);
+/* out_k[j] (+)= sum over the R rows of part_k[r][j], k < 3 (fixed order); _tall: R up to millions via 64-row chunks in ws[ceil(R/64)][n] */
+int se_train_colsum(const float *p0, float *o0, int n0, const float *p1, float *o1, int n1, const float *p2, float *o2, int n2, int R, int accumulate,
+                    void *stream);
+int se_train_colsum_tall(const float *x, int64_t R, int n, float *ws, float *out, int accumulate, void *stream);
+/* decoder skip gate (CRN.py:387-396): uv [S][2Co][T][F] = the stacked 1x1 convolutions (residual | residualmask) of the skip tensor,
+ * z [S][Co][T][F] = padded gLN(act(deconv)); out = m * act(u) + (1 - m) * z, m = sigmoid(gLN(v)) */
+int se_train_skip_fwd(const float *uv, const float *z, const float *nw, const float *nb, float *out, float *stats, int S, int Co, int T, int F, int act,
+                      int eps_mode, void *stream);
+int se_train_skip_bwd(const float *dout, const float *uv, const float *z, const float *nw, const float *nb, const float *stats, float *duv, float *dz,
+                      float *dnw_part, float *dnb_part, float *dbias_part, int S, int Co, int T, int F, int act, int eps_mode, void *stream);
+int se_train_add(float *dst, const float *src, int64_t n, void *stream);
+/* h_{s-1} rows for the recurrent weight gradient (row addressing as se_train_gru_pseq_*) */
+int se_train_gru_hprev(const float *out, const float *h0, float *hp, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, void *stream);
+/* se_train_conv with the weights in their checkpoint layout (element (row, col, kf, kt) at w[row*sCo + col*sCi + kf*3 + kt]); kind 3 =
+ * 1x1 convolution.  ws: se_train_conv_ws_floats() floats of scratch for the staged arrangement. */
+int se_train_conv_ws_floats(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil);
+int se_train_conv_w(int kind, const float *x, const float *xprev, const float *w, int64_t sCo, int64_t sCi, const float *bias, float *y, float *ws,
+                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, void *stream);
+/* deterministic weight gradients: partial tiles per row split into ws[<= 64][...] (fold with se_train_colsum); ntap 15 or 1 */
+int se_train_conv_wgrad_det(const float *G, const float *S, const float *Sprev, float *ws, int *nsplit_out, int B, int Ca, int Cb, int T, int Fm,
+                            int Fs, int dil, int ntap, void *stream);
+int se_train_gemm_tn_det(const float *A, const float *B, float *ws, int *nsplit_out, int64_t R, int Na, int Nb, void *stream);
 
 /* ---- 8f-4: synthetic multi-microphone training data on the GPU (csrc/se_synth.hip) -------------------------------------
  * Replaces the reference's CPU/gpuRIR input pipeline for DP training: multichannel.py:37-103 (Single2Multi.simulate: shoebox

@@ -31,6 +31,10 @@ void launch_k_final_mask_ew(dim3 grid, hipStream_t st, const MaskEwArgs &a) { hi
 void launch_k_fsn_mask(dim3 grid, hipStream_t st, const FsnMaskArgs &a) { hipLaunchKernelGGL(k_fsn_mask, grid, dim3(256), 0, st, a); }
 
 void aux_set_fft_lds(int stft_bytes, int istft_bytes) {
+    // engines / signal handles of different STFT sizes share the kernels: the opt-in only ever grows
+    static int cur_stft = 0, cur_istft = 0;
+    stft_bytes = cur_stft = stft_bytes > cur_stft ? stft_bytes : cur_stft;
+    istft_bytes = cur_istft = istft_bytes > cur_istft ? istft_bytes : cur_istft;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft), hipFuncAttributeMaxDynamicSharedMemorySize, stft_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft), hipFuncAttributeMaxDynamicSharedMemorySize, istft_bytes);
 }

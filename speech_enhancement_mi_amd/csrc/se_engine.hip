@@ -1128,7 +1128,7 @@ int ensure_ready(se_engine *e) {
 
 extern "C" {
 
-int se_abi_version(void) { return 3; }
+int se_abi_version(void) { return 4; }
 
 int se_config_size(void) { return (int)sizeof(se_config); }
 int fsn_config_size(void) { return (int)sizeof(fsn_config); }

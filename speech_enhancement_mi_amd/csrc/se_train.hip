@@ -8,8 +8,13 @@
 #include <cstdio>
 #include <string>
 
+#include <cmath>
+#include <vector>
+
 #include "../../include/se_engine.h"
 #include "gru_pseq.hip.h"
+#include "stft.hip.h"
+#include "train_fused.hip.h"
 
 namespace se {
 
@@ -31,9 +36,26 @@ static int pseq_kj(int H) {  // smallest register block that keeps the K split w
     return 0;
 }
 
+void launch_arrange_w(const float *w, float *out, long sCo, long sCi, int Co, int Ci, int ntap, int CC, int nchunk, int CoPad, int one_by_one,
+                      const int *kf, const int *kt, hipStream_t st) {
+    TArrangeArgs a{};
+    a.w = w; a.out = out; a.sCo = sCo; a.sCi = sCi; a.Co = Co; a.Ci = Ci; a.ntap = ntap; a.CC = CC; a.nchunk = nchunk; a.CoPad = CoPad;
+    a.one_by_one = one_by_one;
+    for (int t = 0; t < ntap && t < 15; t++) { a.tap_kf[t] = kf[t]; a.tap_kt[t] = kt[t]; }
+    const long total = (long)nchunk * ntap * CC * CoPad;
+    hipLaunchKernelGGL(k_arrange_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+
 }  // namespace se
 
 using se::train_fail;
+
+// STFT geometry + tables of the training step's signal stages (the engine's k_stft / k_istft kernels without an engine handle)
+struct se_sig {
+    int device = 0, N = 0, win = 0, hop = 0, K = 0, T = 0, F = 0;
+    float *window = nullptr, *env = nullptr, *tw = nullptr;
+    se::FftPlan plan{};
+};
 
 extern "C" {
 
@@ -80,6 +102,180 @@ int se_train_gru_pseq_bwd(const float *dout, const float *dhT, const float *gate
     se::GruPseqBwdArgs a{dout, dhT, gates, out, h0, whh_t, dgi, dgh, scratch + 16, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, seg_len, (long)ldN, (long)ldB};
     SE_PSEQ_LAUNCH(k_gru_pseq_bwd, a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU backward launch failed");
+}
+
+#define TCHECK(call)                                                                                             \
+    do {                                                                                                         \
+        if ((call) != hipSuccess) return train_fail(SE_ERR_HIP, "%s failed (%s:%d)", #call, __FILE__, __LINE__); \
+    } while (0)
+
+int se_sig_create(int n_fft, int win, int hop, int K, int device, se_sig **out) {
+    if (!out || n_fft <= 0 || n_fft % 2 || win <= 0 || win > n_fft || hop <= 0 || K <= 0 || K % hop) return train_fail(SE_ERR_ARG, "bad STFT geometry");
+    se_sig *g = new se_sig();
+    g->device = device; g->N = n_fft; g->win = win; g->hop = hop; g->K = K; g->T = 1 + K / hop; g->F = n_fft / 2 + 1;
+    g->plan.N = n_fft;
+    g->plan.npass = fft_plan(n_fft / 2, g->plan.radices);
+    if (!g->plan.npass || g->plan.npass > se::kMaxRadices) { delete g; return train_fail(SE_ERR_ARG, "n_fft must factor into 2s and 5s"); }
+    if (hipSetDevice(device) != hipSuccess) { delete g; return train_fail(SE_ERR_HIP, "hipSetDevice failed"); }
+    const int N = n_fft, T = g->T;
+    std::vector<float> w(N, 0.0f), tw(2 * (size_t)N), env(K, 0.0f);
+    const int left = (N - win) / 2;
+    for (int i = 0; i < win; i++) w[left + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / win));
+    for (int i = 0; i < N; i++) { tw[2 * i] = (float)cos(2.0 * M_PI * i / N); tw[2 * i + 1] = (float)-sin(2.0 * M_PI * i / N); }
+    for (int i = 0; i < K; i++) {
+        const int pos = N / 2 + i;
+        float sum = 0;
+        for (int t = 0; t < T; t++) { const int n = pos - t * hop; if (n >= 0 && n < N) sum += w[n] * w[n]; }
+        env[i] = sum;
+    }
+    auto up = [&](float *&d, const std::vector<float> &h) {
+        return hipMalloc(reinterpret_cast<void **>(&d), h.size() * sizeof(float)) == hipSuccess &&
+               hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(g->window, w) || !up(g->tw, tw) || !up(g->env, env)) { se_sig_destroy(g); return train_fail(SE_ERR_HIP, "table upload failed"); }
+    se::aux_set_fft_lds((int)se::stft_lds_bytes(K, N), (int)se::istft_lds_bytes(T, N));
+    *out = g;
+    return SE_OK;
+}
+
+void se_sig_destroy(se_sig *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->window) (void)hipFree(g->window);
+    if (g->tw) (void)hipFree(g->tw);
+    if (g->env) (void)hipFree(g->env);
+    delete g;
+}
+
+int se_sig_stft(se_sig *g, const float *wav, int B, int M, int64_t L, int64_t off0, int64_t seg_off, int nseg, float *spec, void *stream) {
+    if (!g || !wav || !spec || B <= 0 || M <= 0 || nseg <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::StftArgs a{};
+    a.src = wav; a.strideB = (long)M * L; a.strideM = L; a.M = M; a.off = off0; a.L = L;
+    a.K = g->K; a.T = g->T; a.F = g->F; a.hop = g->hop;
+    a.spec = reinterpret_cast<cf2 *>(spec); a.sR = (long)g->T * g->F; a.sT = g->F; a.sF = 1;
+    a.window = g->window; a.tw = reinterpret_cast<const cf2 *>(g->tw); a.plan = g->plan;
+    a.seg_off = seg_off; a.seg_spec = (long)B * M * g->T * g->F;
+    se::launch_k_stft(dim3(B * M, nseg), se::stft_lds_bytes(g->K, g->N), static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "stft launch failed");
+}
+
+int se_sig_istft(se_sig *g, const float *spec, int rows, float *wav, void *stream) {
+    if (!g || !spec || !wav || rows <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::IstftArgs a{};
+    a.spec = reinterpret_cast<const cf2 *>(spec); a.sR = (long)g->T * g->F; a.sT = g->F; a.sF = 1;
+    a.K = g->K; a.T = g->T; a.F = g->F; a.hop = g->hop;
+    a.wav = wav; a.wav_ld = g->K; a.window = g->window; a.env = g->env; a.tw = reinterpret_cast<const cf2 *>(g->tw); a.plan = g->plan;
+    se::launch_k_istft(dim3(rows, 1), se::istft_lds_bytes(g->T, g->N), static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "istft launch failed");
+}
+
+int se_train_ola_fwd(se_sig *g, const float *yseg, float *out, int B, int64_t L, int64_t skip, void *stream) {
+    if (!g || !yseg || !out || B <= 0 || L <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tola_fwd, dim3((unsigned)((L + 255) / 256), B), dim3(256), 0, static_cast<hipStream_t>(stream), yseg, out, B, g->K, (long)L, (long)skip);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_ola_bwd(se_sig *g, const float *dout, float *gseg, int B, int nseg, int64_t L, int64_t skip, void *stream) {
+    if (!g || !dout || !gseg || B <= 0 || nseg <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tola_bwd, dim3((g->K + 255) / 256, B, nseg), dim3(256), 0, static_cast<hipStream_t>(stream), dout, g->env, gseg, B, g->K, (long)L, (long)skip);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_feat(const float *spec, float *feat, int S, int M, int T, int F, int atan2_phase, void *stream) {
+    if (!spec || !feat || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tfeat, dim3((T * F + 255) / 256, S), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const cf2 *>(spec), feat, M, T * F, atan2_phase);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_mask_fwd(const float *x, const float *spec, float *Y, int S, int M, int T, int F, void *stream) {
+    if (!x || !spec || !Y || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tmask_fwd, dim3((T * F + 255) / 256, S), dim3(256), 0, static_cast<hipStream_t>(stream), x, reinterpret_cast<const cf2 *>(spec),
+                       reinterpret_cast<cf2 *>(Y), M, T * F);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_mask_bwd(const float *dY, const float *x, const float *spec, float *dx, int S, int M, int T, int F, int n_fft, void *stream) {
+    if (!dY || !x || !spec || !dx || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tmask_bwd, dim3((T * F + 255) / 256, S), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const cf2 *>(dY), x,
+                       reinterpret_cast<const cf2 *>(spec), dx, M, T, F, 1.0f / (float)n_fft);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_gln_fwd(const float *x, int64_t xS, int64_t xC, int64_t xT, float *y, int64_t yS, int64_t yC, int64_t yT, const float *w, const float *b,
+                     float *stats, int S, int C, int T, int Fi, int Fo, int mode, int act, int eps_mode, void *stream) {
+    if (!x || !y || !w || !b || !stats || S <= 0 || Fo < Fi) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TGlnArgs a{};
+    a.x = x; a.xS = xS; a.xC = xC; a.xT = xT; a.y = y; a.yS = yS; a.yC = yC; a.yT = yT; a.w = w; a.b = b; a.stats = stats;
+    a.C = C; a.T = T; a.Fi = Fi; a.Fo = Fo; a.mode = mode; a.act = act; a.eps_mode = eps_mode;
+    hipLaunchKernelGGL(se::k_tgln_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_gln_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const float *x, int64_t xS, int64_t xC, int64_t xT, float *dx, const float *w,
+                     const float *stats, float *dw_part, float *db_part, float *dpre_part, int S, int C, int T, int Fi, int mode, int act,
+                     int eps_mode, void *stream) {
+    if (!dy || !x || !dx || !w || !stats || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TGlnArgs a{};
+    a.dy = dy; a.dS = dS; a.dC = dC; a.dT = dT; a.x = x; a.xS = xS; a.xC = xC; a.xT = xT; a.y = dx; a.w = w;
+    a.stats = const_cast<float *>(stats); a.dw_part = dw_part; a.db_part = db_part; a.dpre_part = dpre_part;
+    a.C = C; a.T = T; a.Fi = Fi; a.Fo = Fi; a.mode = mode; a.act = act; a.eps_mode = eps_mode;
+    if (mode) hipLaunchKernelGGL(se::k_tgln_bwd_d, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(se::k_tgln_bwd_c, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_colsum(const float *p0, float *o0, int n0, const float *p1, float *o1, int n1, const float *p2, float *o2, int n2, int R, int accumulate,
+                    void *stream) {
+    if (!p0 || !o0 || n0 <= 0 || R <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TColsumArgs a{};
+    a.part[0] = p0; a.out[0] = o0; a.n[0] = n0; a.part[1] = p1; a.out[1] = o1; a.n[1] = n1; a.part[2] = p2; a.out[2] = o2; a.n[2] = n2;
+    a.R = R; a.accumulate = accumulate;
+    const int nmax = std::max(n0, std::max(p1 ? n1 : 0, p2 ? n2 : 0));
+    hipLaunchKernelGGL(se::k_colsum, dim3((nmax + 255) / 256, p2 ? 3 : (p1 ? 2 : 1)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+/* out[j] (+)= sum_r x[r][j] for a tall matrix: chunks of 64 rows into ws[ceil(R/64)][n], then a fixed-order fold */
+int se_train_colsum_tall(const float *x, int64_t R, int n, float *ws, float *out, int accumulate, void *stream) {
+    if (!x || !ws || !out || R <= 0 || n <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nch = (int)((R + 63) / 64);
+    hipLaunchKernelGGL(se::k_colsum_chunks, dim3((n + 255) / 256, nch), dim3(256), 0, st, x, ws, (int)R, n);
+    se::TColsumArgs a{};
+    a.part[0] = ws; a.out[0] = out; a.n[0] = n; a.R = nch; a.accumulate = accumulate;
+    hipLaunchKernelGGL(se::k_colsum, dim3((n + 255) / 256, 1), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_skip_fwd(const float *uv, const float *z, const float *nw, const float *nb, float *out, float *stats, int S, int Co, int T, int F, int act,
+                      int eps_mode, void *stream) {
+    if (!uv || !z || !nw || !nb || !out || !stats || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TSkipArgs a{};
+    a.uv = uv; a.z = z; a.nw = nw; a.nb = nb; a.out = out; a.stats = stats; a.Co = Co; a.T = T; a.F = F; a.act = act; a.eps_mode = eps_mode;
+    hipLaunchKernelGGL(se::k_tskip_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_skip_bwd(const float *dout, const float *uv, const float *z, const float *nw, const float *nb, const float *stats, float *duv, float *dz,
+                      float *dnw_part, float *dnb_part, float *dbias_part, int S, int Co, int T, int F, int act, int eps_mode, void *stream) {
+    if (!dout || !uv || !z || !nw || !nb || !stats || !duv || !dz || !dnw_part || !dnb_part || !dbias_part || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TSkipArgs a{};
+    a.dout = dout; a.uv = uv; a.z = z; a.nw = nw; a.nb = nb; a.stats = const_cast<float *>(stats); a.duv = duv; a.dz = dz;
+    a.dnw_part = dnw_part; a.dnb_part = dnb_part; a.dbias_part = dbias_part; a.Co = Co; a.T = T; a.F = F; a.act = act; a.eps_mode = eps_mode;
+    hipLaunchKernelGGL(se::k_tskip_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_add(float *dst, const float *src, int64_t n, void *stream) {
+    if (!dst || !src || n <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tadd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, (long)n);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_gru_hprev(const float *out, const float *h0, float *hp, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, void *stream) {
+    if (!out || !h0 || !hp || B <= 0 || T <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_gru_hprev, dim3((H + 255) / 256, T, B), dim3(256), 0, static_cast<hipStream_t>(stream), out, h0, hp, B, T, H, Tseg, (long)ldN, (long)ldB);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
 }  // extern "C"

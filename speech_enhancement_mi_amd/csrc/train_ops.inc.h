@@ -12,7 +12,11 @@
 // Everything is fp32 with exact MFMA accumulation order (v_mfma_f32_32x32x2_f32 / 16x16x4), so gradients agree with torch
 // autograd to rounding; the checker is tests/test_gpu_round2.py::test_hip_training_ops_vs_autograd.
 
-namespace se { int train_fail(int code, const char *fmt, ...); }  // se_train.hip (owns se_train_last_error)
+namespace se {
+int train_fail(int code, const char *fmt, ...);  // se_train.hip (owns se_train_last_error)
+void launch_arrange_w(const float *w, float *out, long sCo, long sCi, int Co, int Ci, int ntap, int CC, int nchunk, int CoPad, int one_by_one,
+                      const int *kf, const int *kt, hipStream_t st);
+}
 #define tfail se::train_fail
 
 namespace {
@@ -42,9 +46,14 @@ int train_conv_geometry(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil
         for (int kf = 1; kf < 5; kf += 2)
             for (int kt = 0; kt < 3; kt++) taps.push_back({kf, kt, 2 - kt, 1 + (3 - kf) / 2});
         FP = Fy / 2; s = 1; os = 2; oo = 1; colpad = 1; tlo_off = 0; St = Fi + 2;
+    } else if (kind == 3) {  // 1x1 convolution (the decoder's stacked residual / residualmask pair, CRN.py:372-375, and its input gradient)
+        taps.push_back({2, 2, 0, 0});
+        FP = Fy; s = 1; os = 1; oo = 0; colpad = 0; tlo_off = 0; St = Fi; dil = 0;
+        if (Fy != Fi) return tfail(SE_ERR_ARG, "1x1 conv: Fy must equal Fi");
     } else return tfail(SE_ERR_ARG, "unknown conv kind %d", kind);
-    if (kind != 0 && (Fy < 2 * Fi - 1 || Fy > 2 * Fi)) return tfail(SE_ERR_ARG, "transposed conv: Fy must be 2 Fi - 1 or 2 Fi");
-    const int ntap = (int)taps.size(), ngroup = 3;
+    if ((kind == 1 || kind == 2) && (Fy < 2 * Fi - 1 || Fy > 2 * Fi)) return tfail(SE_ERR_ARG, "transposed conv: Fy must be 2 Fi - 1 or 2 Fi");
+    if (kind != 3 && T <= 2 * dil) return tfail(SE_ERR_ARG, "segment of %d frames is not longer than the dilation history 2 x %d (CRN.py:333-337 keeps older columns then; unsupported)", T, dil);
+    const int ntap = (int)taps.size(), ngroup = kind == 3 ? 1 : 3;
     const int P = T * FP, tiles = (P + 31) / 32;
     const int CoPad = (Co + 31) / 32 * 32;
     if (CoPad > 128 || CoPad == 96) return tfail(SE_ERR_ARG, "%d output channels unsupported (32, 64 or 128 GEMM rows)", Co);
@@ -83,6 +92,15 @@ int train_conv_geometry(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil
     return 0;
 }
 
+void train_conv_attributes() {  // large dynamic LDS opt-in of every convolution instance: once per process and device
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_dev == dev) return;
+    conv_set_attributes();
+    done_dev = dev;
+}
+
 }  // namespace
 
 namespace se {
@@ -97,6 +115,8 @@ struct WgradArgs {
     const float *G, *S, *Sprev;
     float *C;
     int B, Ca, Cb, T, Fm, Fs, dil, rows_per_split;
+    int ntap, fs;  // 15 taps with frequency stride 2 (5x3 kernels), or ntap = 1, fs = 1 (1x1 convolutions)
+    long split_stride;  // > 0: split z writes its partial tile to C + z * split_stride (deterministic two-stage sum); 0: atomics into C
 };
 
 __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
@@ -104,10 +124,11 @@ __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int a0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const int N = a.Cb * 15;
+    const int N = a.Cb * a.ntap;
     const int ai = a0 + l31, n = n0 + l31;
     const bool a_ok = ai < a.Ca, n_ok = n < N;
-    const int bch = n_ok ? n / 15 : 0, tap = n_ok ? n - bch * 15 : 0, kf = tap / 3, kt = tap - kf * 3;
+    const int bch = n_ok ? n / a.ntap : 0, tap = n_ok ? n - bch * a.ntap : 0;
+    const int kf = a.ntap == 1 ? 2 : tap / 3, kt = a.ntap == 1 ? 2 : tap - kf * 3;
     const int toff = -(2 - kt) * a.dil;
     f32x16 acc;
 #pragma unroll
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
         for (int m = 0; m < a.Fm; m += 2) {
             const int mm = m + kh;
             const float av = (a_ok && mm < a.Fm) ? gp[mm] : 0.0f;
-            const int f = 2 * mm + kf - 2;
+            const int f = a.fs * mm + kf - 2;
             const float bv = (s_ok && mm < a.Fm && f >= 0 && f < a.Fs) ? sp[f] : 0.0f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
@@ -140,7 +161,12 @@ __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (arow < a.Ca) atomicAdd(a.C + ((long)arow * a.Cb + bch) * 15 + tap, acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]);
+            if (arow < a.Ca) {
+                const float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+                float *dst = a.C + ((long)arow * a.Cb + bch) * a.ntap + tap;
+                if (a.split_stride) dst[(long)blockIdx.z * a.split_stride] = v;
+                else atomicAdd(dst, v);
+            }
         }
     }
 }
@@ -259,6 +285,7 @@ struct GemmTnArgs {
     float *C;
     long R, rows_per_split;
     int Na, Nb;
+    long split_stride;  // > 0: split z writes its partial tile to C + z * split_stride (no atomics); 0: atomicAdd into C
 };
 
 __global__ __launch_bounds__(256) void k_gemm_tn_acc(GemmTnArgs a) {
@@ -295,7 +322,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn_acc(GemmTnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (i < a.Na) atomicAdd(a.C + (long)i * a.Nb + j0 + l31, acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]);
+            if (i < a.Na) {
+                const float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+                float *dst = a.C + (long)i * a.Nb + j0 + l31;
+                if (a.split_stride) dst[(long)blockIdx.z * a.split_stride] = v;
+                else atomicAdd(dst, v);
+            }
         }
     }
 }
@@ -428,7 +460,7 @@ int se_train_conv(int kind, const float *x, const float *xprev, const float *w_a
     ConvArgs a = g.a;
     a.x = x; a.xprev = xprev; a.w = w_arranged; a.bias = bias; a.y = y;
     a.act = act; a.relu_lo = 0; a.relu_hi = act ? Co : 0;
-    conv_set_attributes();
+    train_conv_attributes();
     if (conv_igemm_launch(a.ntap, g.NT, a.CoPad, dim3(g.grid_x, B), g.lds, static_cast<hipStream_t>(stream), a))
         return tfail(SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, g.NT);
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "conv launch failed");
@@ -443,9 +475,52 @@ int se_train_conv_wgrad(const float *G, const float *S, const float *Sprev, floa
     int nsplit = std::max(1, std::min(nrows / 4, (4 * 256 + tiles - 1) / tiles));  // ~4 workgroups per CU over the whole grid
     const int rows_per_split = (nrows + nsplit - 1) / nsplit;
     nsplit = (nrows + rows_per_split - 1) / rows_per_split;
-    se::WgradArgs a{G, S, Sprev, C, B, Ca, Cb, T, Fm, Fs, dil, rows_per_split};
+    se::WgradArgs a{G, S, Sprev, C, B, Ca, Cb, T, Fm, Fs, dil, rows_per_split, 15, 2, 0};
     hipLaunchKernelGGL(se::k_corr_wgrad, dim3((Cb * 15 + 31) / 32, (Ca + 31) / 32, nsplit), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "wgrad launch failed");
+}
+
+/* Deterministic weight gradient (no atomics): the (batch, t) rows are split over `nsplit` workgroup layers which write partial
+ * tiles to ws[nsplit][Ca*Cb*ntap]; se_train_colsum folds them in a fixed order.  ntap = 15 (5x3 kernels, frequency stride 2) or
+ * 1 (1x1 convolutions).  Returns the number of splits through *nsplit_out; ws needs se_train_wgrad_ws_floats() floats. */
+int se_train_conv_wgrad_det(const float *G, const float *S, const float *Sprev, float *ws, int *nsplit_out, int B, int Ca, int Cb, int T, int Fm,
+                            int Fs, int dil, int ntap, void *stream) {
+    if (!G || !S || !ws || !nsplit_out || B <= 0 || (ntap != 15 && ntap != 1)) return tfail(SE_ERR_ARG, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nrows = B * T, ncol = Cb * ntap, tiles = ((ncol + 31) / 32) * ((Ca + 31) / 32);
+    int nsplit = std::max(1, std::min(std::min(nrows / 4, 64), (4 * 256 + tiles - 1) / tiles));
+    const int rows_per_split = (nrows + nsplit - 1) / nsplit;
+    nsplit = (nrows + rows_per_split - 1) / rows_per_split;
+    se::WgradArgs a{G, S, Sprev, ws, B, Ca, Cb, T, Fm, Fs, dil, rows_per_split, ntap, ntap == 1 ? 1 : 2, (long)Ca * Cb * ntap};
+    hipLaunchKernelGGL(se::k_corr_wgrad, dim3((ncol + 31) / 32, (Ca + 31) / 32, nsplit), dim3(256), 0, st, a);
+    *nsplit_out = nsplit;
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "wgrad launch failed");
+}
+
+/* se_train_conv with the weights in their checkpoint layout: element (co, ci, kf, kt) of the GEMM-row-major view at
+ * w[co * sCo + ci * sCi + kf * 3 + kt] (Conv2d: sCo = Ci*15, sCi = 15; ConvTranspose2d [Cin][Cout][5][3] read with rows = its Cout:
+ * sCo = 15, sCi = Cout*15; 1x1: sCo = Ci, sCi = 1 or transposed).  The arrangement the kernel stages is made on the device into `ws`
+ * (se_train_conv_ws_floats() floats) by one small launch ahead of the convolution: no host-side tensor shuffling per step. */
+int se_train_conv_ws_floats(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil) {
+    TrainConvGeo g;
+    if (train_conv_geometry(kind, Ci, Co, T, Fi, Fy, dil, g)) return -1;
+    return g.a.nchunk * g.a.ntap * g.a.CC * g.a.CoPad;
+}
+int se_train_conv_w(int kind, const float *x, const float *xprev, const float *w, int64_t sCo, int64_t sCi, const float *bias, float *y, float *ws,
+                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, void *stream) {
+    if (!x || !w || !bias || !y || !ws || B <= 0) return tfail(SE_ERR_ARG, "null argument");
+    TrainConvGeo g;
+    int rc = train_conv_geometry(kind, Ci, Co, T, Fi, Fy, dil, g);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    se::launch_arrange_w(w, ws, (long)sCo, (long)sCi, Co, Ci, g.a.ntap, g.a.CC, g.a.nchunk, g.a.CoPad, kind == 3, g.tap_kf, g.tap_kt, st);
+    ConvArgs a = g.a;
+    a.x = x; a.xprev = xprev; a.w = ws; a.bias = bias; a.y = y;
+    a.act = act; a.relu_lo = 0; a.relu_hi = act ? Co : 0;
+    train_conv_attributes();
+    if (conv_igemm_launch(a.ntap, g.NT, a.CoPad, dim3(g.grid_x, B), g.lds, st, a))
+        return tfail(SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, g.NT);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "conv launch failed");
 }
 
 int se_train_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, void *stream) {
@@ -465,8 +540,22 @@ int se_train_gemm_tn(const float *A, const float *B, float *C, int64_t R, int Na
     long nsplit = std::max<long>(1, std::min<long>((R + 255) / 256, (4 * 256 + tiles - 1) / tiles));  // ~4 workgroups per CU, >= 256 rows each
     const long rows_per_split = ((R + nsplit - 1) / nsplit + 7) / 8 * 8;
     nsplit = (R + rows_per_split - 1) / rows_per_split;
-    se::GemmTnArgs a{A, B, C, (long)R, rows_per_split, Na, Nb};
+    se::GemmTnArgs a{A, B, C, (long)R, rows_per_split, Na, Nb, 0};
     hipLaunchKernelGGL(se::k_gemm_tn_acc, dim3((Nb + 31) / 32, (Na + 31) / 32, (unsigned)nsplit), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm_tn launch failed");
+}
+
+/* deterministic form: partial tiles per row split to ws[nsplit][Na*Nb] (<= 64 splits), folded by se_train_colsum */
+int se_train_gemm_tn_det(const float *A, const float *B, float *ws, int *nsplit_out, int64_t R, int Na, int Nb, void *stream) {
+    if (!A || !B || !ws || !nsplit_out || R <= 0 || Na <= 0 || Nb <= 0) return tfail(SE_ERR_ARG, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tiles = ((Na + 31) / 32) * ((Nb + 31) / 32);
+    long nsplit = std::max<long>(1, std::min<long>(std::min<long>((R + 255) / 256, 64), (4 * 256 + tiles - 1) / tiles));
+    const long rows_per_split = ((R + nsplit - 1) / nsplit + 7) / 8 * 8;
+    nsplit = (R + rows_per_split - 1) / rows_per_split;
+    se::GemmTnArgs a{A, B, ws, (long)R, rows_per_split, Na, Nb, (long)Na * Nb};
+    hipLaunchKernelGGL(se::k_gemm_tn_acc, dim3((Nb + 31) / 32, (Na + 31) / 32, (unsigned)nsplit), dim3(256), 0, st, a);
+    *nsplit_out = (int)nsplit;
     return hipGetLastError() == hipSuccess ? SE_OK : tfail(SE_ERR_HIP, "gemm_tn launch failed");
 }
 

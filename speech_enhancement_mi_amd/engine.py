@@ -23,7 +23,10 @@ EXPORTS = [
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
     "se_train_last_error", "se_train_conv_layout_query", "se_train_conv", "se_train_conv_wgrad", "se_train_gemm", "se_train_gemm_tn", "se_train_gru_step",
-    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd", "se_synth_last_error", "se_synth_rir", "se_synth_fir", "se_synth_mix",
+    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd",
+    "se_sig_create", "se_sig_destroy", "se_sig_stft", "se_sig_istft", "se_train_ola_fwd", "se_train_ola_bwd", "se_train_feat", "se_train_mask_fwd",
+    "se_train_mask_bwd", "se_train_gln_fwd", "se_train_gln_bwd", "se_train_colsum", "se_train_colsum_tall", "se_train_skip_fwd", "se_train_skip_bwd",
+    "se_train_add", "se_train_gru_hprev", "se_train_conv_ws_floats", "se_train_conv_w", "se_train_conv_wgrad_det", "se_train_gemm_tn_det", "se_synth_last_error", "se_synth_rir", "se_synth_fir", "se_synth_mix",
 ]
 
 
@@ -111,6 +114,28 @@ def load_library():
     L.se_train_gru_pseq_supported.argtypes = [i32, i32]
     L.se_train_gru_pseq_fwd.argtypes = [vp] * 8 + [i32, i32, i32, i32, i64, i64, vp]
     L.se_train_gru_pseq_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, i64, i64, i32, vp]
+    L.se_sig_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.se_sig_destroy.argtypes = [vp]
+    L.se_sig_destroy.restype = None
+    L.se_sig_stft.argtypes = [vp, vp, i32, i32, i64, i64, i64, i32, vp, vp]
+    L.se_sig_istft.argtypes = [vp, vp, i32, vp, vp]
+    L.se_train_ola_fwd.argtypes = [vp, vp, vp, i32, i64, i64, vp]
+    L.se_train_ola_bwd.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp]
+    L.se_train_feat.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.se_train_mask_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    L.se_train_mask_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.se_train_gln_fwd.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, vp, vp, vp] + [i32] * 8 + [vp]
+    L.se_train_gln_bwd.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp] + [i32] * 7 + [vp]
+    L.se_train_colsum.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    L.se_train_colsum_tall.argtypes = [vp, i64, i32, vp, vp, i32, vp]
+    L.se_train_skip_fwd.argtypes = [vp] * 6 + [i32] * 6 + [vp]
+    L.se_train_skip_bwd.argtypes = [vp] * 11 + [i32] * 6 + [vp]
+    L.se_train_add.argtypes = [vp, vp, i64, vp]
+    L.se_train_gru_hprev.argtypes = [vp, vp, vp, i32, i32, i32, i32, i64, i64, vp]
+    L.se_train_conv_ws_floats.argtypes = [i32] * 7
+    L.se_train_conv_w.argtypes = [i32, vp, vp, vp, i64, i64, vp, vp, vp] + [i32] * 8 + [vp]
+    L.se_train_conv_wgrad_det.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int)] + [i32] * 8 + [vp]
+    L.se_train_gemm_tn_det.argtypes = [vp, vp, vp, C.POINTER(C.c_int), i64, i32, i32, vp]
     L.se_synth_last_error.restype = C.c_char_p
     L.se_synth_rir.argtypes = [vp, vp, vp, vp] + [i32] * 6 + [C.c_float, C.c_float, i32, vp, vp]
     L.se_synth_fir.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp, vp]

@@ -1,13 +1,15 @@
 """Data-parallel training path (BASELINE config 4): utterances sharded across the GPUs of one node,
 ONE flat fp32 gradient bucket all-reduced per optimizer step over RCCL/xGMI.
 
-Scope of this round: the inference hot path is hand-written HIP; the *training* forward/backward here is a PyTorch-ROCm
-autograd restatement of the same arithmetic (SURVEY.md 7 step 8 - hand-written backward kernels are ranked "next", 8f-1),
-so what this module adds is (a) a differentiable `TrainableCRN` whose forward is pinned against the CPU oracle
-(tests/test_training_cpu.py), (b) the flat-bucket gradient all-reduce the reference never had (its DDP lines are
-commented out, train.py:172-173,252-256), and (c) the optimizer step of the reference trainer (Adam 3e-4, grad-accum 2,
-clip 5; train.py:198-204, config.yaml:9,99).  Loss: the SI-SNR term of compute_loss (CRN.py:609-611); the STOI term needs
-torchaudio 0.7.2 semantics that are unpinned here (losses.py) and is left out - stated, not hidden.
+`TrainableCRN` has two interchangeable differentiable forwards of `realtime_process` (CRN.py:560-589):
+  * `use_hip_kernels(True)`: every stage forward AND backward on the hand-written kernels (train_net.CRNFunction;
+    SURVEY.md 8f-1) - the path bench.py --mode train times;
+  * default: a PyTorch autograd restatement of the same arithmetic, CPU-runnable, pinned against the CPU oracle
+    (tests/test_training_cpu.py) - the checker the GPU tests compare the kernels with.
+Around it: the flat-bucket gradient all-reduce the reference never had (its DDP lines are commented out,
+train.py:172-173,252-256) and the optimizer step of the reference trainer (Adam 3e-4, grad-accum 2, clip 5;
+train.py:198-204, config.yaml:9,99).  Loss: `compute_loss` = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611; losses.py:
+HIP SI-SNR kernels + the batched device-resident STOI restatement, torchaudio boundary unpinned) or the SI-SNR term alone.
 """
 from __future__ import annotations
 
@@ -42,12 +44,16 @@ class TrainableCRN(TemporalCRN):
         self._nfft = c["n_fft"]
         self._state = None
         self._hip = False
-        self.batch_segments = True  # HIP path: every layer once over B x N segment streams (False: one segment at a time)
+        self._hip_state_from_torch = False
 
     def use_hip_kernels(self, flag=True):
-        """True: convolutions, transposed convolutions, the GRU and the dense layers run forward AND backward on the
-        hand-written kernels of csrc/train_ops.inc.h (train_ops.py); False: torch ops + autograd (the checker)."""
+        """True: the whole differentiable realtime_process - STFT, features, convolutions, norms, GRU, dense layers, skip gates,
+        mask, iSTFT, overlap-add - runs forward AND backward on the hand-written kernels (train_net.CRNFunction: one autograd
+        node, no float atomics); False (default): torch ops + autograd, the CPU-runnable checker the tests pin to the oracle."""
+        if bool(flag) != self._hip:
+            self._state = None  # the two paths keep their carried state in different layouts
         self._hip = bool(flag)
+        self._hip_state_from_torch = False
         return self
 
     # ---- signal glue (utility.py:312-403, CRN.py:505-520) ----
@@ -117,123 +123,13 @@ class TrainableCRN(TemporalCRN):
         Y = torch.complex(m[:, 0] * re[:, 0] - m[:, 1] * im[:, 0], m[:, 1] * re[:, 0] + m[:, 0] * im[:, 0])
         return Y, dict(buf=new_buf, h=h.detach())
 
-    # ---- one segment on the hand-written kernels; activations [B, C, T, F] (F innermost, the engine's layout) ----
-    def _forward_segment_hip(self, X, state):
-        from . import train_ops as K
-        re, im = X.real, X.imag  # [B, M, F, T]
-        ang = torch.atan(im / (re + EPS) + EPS)
-        mag = torch.sqrt(re ** 2 + im ** 2 + 1e-10)
-        x = torch.cat([mag, ang[:, :1] - ang[:, 1:]], dim=1).permute(0, 1, 3, 2).contiguous()  # [B, 5, T, F]
-        residuals = [x]
-        new_buf = []
-        for i, blk in enumerate(self.convlist):
-            prev = state["buf"][i] if state["buf"] is not None else None  # the whole previous input: its last 2d columns are the buffer
-            y = K.conv_block(x, prev, blk.conv.weight, blk.conv.bias, 2 ** i)
-            new_buf.append(x.detach())
-            x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
-            residuals.append(x)
-        B, C, T, Fq = x.shape
-        seq = x.permute(0, 2, 1, 3).reshape(B, T, C * Fq)  # feature index c * F + f (CRN.py:476-478)
-        g = self.gru.sequence_model
-        hs = []
-        for l in range(g.num_layers):
-            h0 = state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size)
-            seq, hT = K.gru_layer(seq, h0, getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}"))
-            hs.append(hT.detach())
-        o = torch.relu(K.linear(seq, self.gru.fc_output_layer.weight, self.gru.fc_output_layer.bias))
-        o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
-        x = o.reshape(B, T, C, Fq).permute(0, 2, 1, 3).contiguous()
-        L = len(self.deconvlist)
-
-        def conv1x1(t, mod):  # [B, C, T, F] x [Co, C, 1, 1] through the GEMM kernel
-            w = mod.weight.reshape(mod.weight.shape[0], -1)
-            return K.linear(t.permute(0, 2, 3, 1), w, mod.bias).permute(0, 3, 1, 2)
-
-        for j, blk in enumerate(self.deconvlist):
-            y = K.deconv_block(x, blk.conv.weight, blk.conv.bias, 2 ** j)
-            y = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
-            if j < L - 1:
-                res = residuals[-2 - j]
-                if res.shape[3] > y.shape[3]:
-                    y = Fn.pad(y, (0, res.shape[3] - y.shape[3]))
-                elif res.shape[3] < y.shape[3]:
-                    y = y[..., :res.shape[3]]
-                m = torch.sigmoid(_gln(conv1x1(res, blk.residualmask), blk.residualnorm.weight, blk.residualnorm.bias))
-                y = m * torch.relu(conv1x1(res, blk.residual)) + (1.0 - m) * y
-            x = y
-        m = x.clamp(-9.9, 9.9)
-        m = -10.0 * torch.log((10.0 - m) / (10.0 + m))
-        mr, mi = m[:, 0].transpose(1, 2), m[:, 1].transpose(1, 2)  # back to [B, F, T]
-        Y = torch.complex(mr * re[:, 0] - mi * im[:, 0], mi * re[:, 0] + mr * im[:, 0])
-        return Y, dict(buf=new_buf, h=hs)
-
-    # ---- ALL segments of a batch at once on the hand-written kernels ----
-    def _forward_all_hip(self, X, state):
-        """X [B, M, N, F, T] complex -> Y [B, N, F, T] complex.  The per-segment loop of realtime_process (CRN.py:577-586) is
-        sequential only through the GRU state: a convolution's time buffer is the PREVIOUS segment's (detached) input of the
-        same block (CRN.py:325-337), every norm is per segment, so each layer runs once over B x N streams with the history
-        tensor = the input shifted by one segment.  Same arithmetic as _forward_segment_hip, 34x fewer launches."""
-        from . import train_ops as K
-        B, M, N, Fq0, T = X.shape
-        Xs = X.permute(0, 2, 1, 3, 4).reshape(B * N, M, Fq0, T)
-        re, im = Xs.real, Xs.imag
-        ang = torch.atan(im / (re + EPS) + EPS)
-        mag = torch.sqrt(re ** 2 + im ** 2 + 1e-10)
-        x = torch.cat([mag, ang[:, :1] - ang[:, 1:]], dim=1).permute(0, 1, 3, 2).contiguous()  # [B*N, 5, T, F]
-
-        def shifted(t, first):  # history of segment n = input of segment n - 1 (state / zeros for n = 0), no gradient
-            tv = t.detach().reshape(B, N, *t.shape[1:])
-            head = first[:, None] if first is not None else torch.zeros_like(tv[:, :1])
-            return torch.cat([head, tv[:, :-1]], dim=1).reshape(t.shape)
-
-        residuals = [x]
-        new_buf = []
-        for i, blk in enumerate(self.convlist):
-            prev = shifted(x, state["buf"][i] if state["buf"] is not None else None)
-            y = K.conv_block(x, prev, blk.conv.weight, blk.conv.bias, 2 ** i)
-            new_buf.append(x.detach().reshape(B, N, *x.shape[1:])[:, -1].contiguous())
-            x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
-            residuals.append(x)
-        BN, C, T, Fq = x.shape
-        seq = x.permute(0, 2, 1, 3).reshape(B, N * T, C * Fq)
-        g = self.gru.sequence_model
-        hs = []
-        for l in range(g.num_layers):  # the recurrence: ONE pass over the N * T steps of every utterance; the carried state is
-            # detached at every segment seam (CRN.py:281), which seg_len = T reproduces in the backward sweep
-            h0 = state["h"][l] if state["h"] is not None else seq.new_zeros(B, g.hidden_size)
-            seq, hT = K.gru_layer(seq, h0, getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"),
-                                  getattr(g, f"bias_hh_l{l}"), seg_len=T)
-            hs.append(hT.detach())
-        o = seq.reshape(BN, T, -1)
-        o = torch.relu(K.linear(o, self.gru.fc_output_layer.weight, self.gru.fc_output_layer.bias))
-        o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
-        x = o.reshape(BN, T, C, Fq).permute(0, 2, 1, 3).contiguous()
-        L = len(self.deconvlist)
-
-        def conv1x1(t, mod):
-            w = mod.weight.reshape(mod.weight.shape[0], -1)
-            return K.linear(t.permute(0, 2, 3, 1), w, mod.bias).permute(0, 3, 1, 2)
-
-        for j, blk in enumerate(self.deconvlist):
-            y = K.deconv_block(x, blk.conv.weight, blk.conv.bias, 2 ** j)
-            y = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
-            if j < L - 1:
-                res = residuals[-2 - j]
-                if res.shape[3] > y.shape[3]:
-                    y = Fn.pad(y, (0, res.shape[3] - y.shape[3]))
-                elif res.shape[3] < y.shape[3]:
-                    y = y[..., :res.shape[3]]
-                m = torch.sigmoid(_gln(conv1x1(res, blk.residualmask), blk.residualnorm.weight, blk.residualnorm.bias))
-                y = m * torch.relu(conv1x1(res, blk.residual)) + (1.0 - m) * y
-            x = y
-        m = x.clamp(-9.9, 9.9)
-        m = -10.0 * torch.log((10.0 - m) / (10.0 + m))
-        mr, mi = m[:, 0].transpose(1, 2), m[:, 1].transpose(1, 2)  # [B*N, F, T]
-        Y = torch.complex(mr * re[:, 0] - mi * im[:, 0], mi * re[:, 0] + mr * im[:, 0])
-        return Y.reshape(B, N, *Y.shape[1:]), dict(buf=new_buf, h=hs)
-
     def realtime_process_train(self, mixture, flag=False):
         """Differentiable realtime_process (CRN.py:560-589): [B, M, L] -> [B, L]."""
+        if self._hip:  # every stage forward and backward on the hand-written kernels, one autograd node (train_net.py)
+            from .train_net import realtime_process_fused
+            if self._hip_state_from_torch:
+                raise RuntimeError("flag=True continuation across a use_hip_kernels() switch is not supported: start with flag=False")
+            return realtime_process_fused(self, mixture, flag)
         K = self.segment_length
         P = K // 2
         if not flag:
@@ -242,16 +138,11 @@ class TrainableCRN(TemporalCRN):
         seg, gap = self._segment(mixture)  # [B, M, N, K]
         X = self._stft(seg)  # [B, M, N, F, T]
         state = self._state
-        if self._hip and self.batch_segments:
-            Y, state = self._forward_all_hip(X, state)
-            y = self._istft(Y)  # [B, N, K]
-        else:
-            outs = []
-            seg_fn = self._forward_segment_hip if self._hip else self._forward_segment
-            for n in range(X.shape[2]):
-                Y, state = seg_fn(X[:, :, n], state)
-                outs.append(self._istft(Y))
-            y = torch.stack(outs, dim=1)  # [B, N, K]
+        outs = []
+        for n in range(X.shape[2]):
+            Y, state = self._forward_segment(X[:, :, n], state)
+            outs.append(self._istft(Y))
+        y = torch.stack(outs, dim=1)  # [B, N, K]
         self._state = state
         B, N, _ = y.shape
         s1 = y[:, 0::2].reshape(B, -1)[:, P:]
@@ -298,24 +189,42 @@ class FlatBucket:
         return norm
 
 
-def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr"):
+def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr", merge=None):
     """One optimizer step of the reference trainer (train.py:195-204) under data parallelism: `accum` micro-batches of local
     utterances, one flat all-reduce, clip 5, Adam.  loss = "full": 0.7 * stoi_loss + 0.3 * (-SI-SNR) (compute_loss,
-    CRN.py:609-611); "sisnr": the SI-SNR term alone."""
+    CRN.py:609-611); "sisnr": the SI-SNR term alone.
+
+    merge (default: on for the hand-written kernels): gradient accumulation exists to bound memory; every statistic of the model
+    is per utterance, so the `accum` micro-batches can share ONE forward / backward sweep (half the dependent GRU steps) while
+    the loss is still formed per micro-batch, sum_i loss(micro-batch i) / accum - the same function of the parameters, hence
+    the same gradient up to fp32 summation order (tests/test_gpu_round3.py::test_merged_microbatches_give_the_accumulated_gradient).
+    merge=False runs the micro-batches one after the other like the reference loop."""
     bucket.zero()
     total = 0.0
-    chunks = mixture.chunk(accum)
-    for i, mix in enumerate(chunks):
-        src = source.chunk(accum)[i]
-        ln = None if length is None else length.chunk(accum)[i]
-        pred = model.realtime_process_train(mix)
+    if merge is None:
+        merge = model._hip
+    srcs = source.chunk(accum)
+    lens = [None] * len(srcs) if length is None else list(length.chunk(accum))
+
+    def loss_of(pred, src, ln):
         if loss == "full":
-            lens = ln if ln is not None else torch.full((mix.shape[0],), mix.shape[-1], dtype=torch.int64)
-            val = model.compute_loss(src, pred, lens)[0] / accum
-        else:
-            val = si_snr_loss(pred, src, ln) / accum
+            ll = ln if ln is not None else torch.full((pred.shape[0],), pred.shape[-1], dtype=torch.int64, device=pred.device)
+            return model.compute_loss(src, pred, ll)[0] / accum
+        return si_snr_loss(pred, src, ln) / accum
+
+    if merge:
+        pred = model.realtime_process_train(mixture)
+        val = None
+        for p_i, src, ln in zip(pred.chunk(accum), srcs, lens):
+            v = loss_of(p_i, src, ln)
+            val = v if val is None else val + v
         val.backward()
-        total += float(val.detach())
+        total = float(val.detach())
+    else:
+        for mix, src, ln in zip(mixture.chunk(accum), srcs, lens):
+            val = loss_of(model.realtime_process_train(mix), src, ln)
+            val.backward()
+            total += float(val.detach())
     if model._hip:
         from . import train_ops
         train_ops.pseq_check()  # a persistent GRU launch that gave up its bounded spin must not go unnoticed

@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in se_engine.h but not exported by libse_engine.so"
     assert sorted(engine.EXPORTS) == names
-    assert lib.se_abi_version() == 3
+    assert lib.se_abi_version() == 4
 
 
 def test_no_cpu_fallback():

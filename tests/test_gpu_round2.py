@@ -389,27 +389,26 @@ def test_preconv_blocks_on_plane_path_match_vector_kernel(monkeypatch, variant):
         assert a.shape == b.shape and rel_rms(a, b) < 1e-6
 
 
-def test_segment_batched_training_forward_equals_per_segment():
-    """The training forward runs every layer once over B x N segment streams (history = the input shifted by one segment,
-    GRU state carried segment by segment).  Same outputs, continuation state and gradients as one segment at a time
-    (CRN.py:577-586), including a flag=True continuation call."""
+def test_fused_training_forward_equals_per_segment_autograd():
+    """The fused training path runs every layer once over N x B segment streams (segment-major; history = the same tensor one
+    slab earlier; GRU state carried segment by segment inside one persistent launch).  Same outputs, continuation state and
+    gradients as the torch-autograd path that walks one segment at a time (CRN.py:577-586), including a flag=True continuation."""
     from speech_enhancement_mi_amd.training import TrainableCRN
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of(FULL400), seed=6).items()}
     mix, clean = synth.synth_utterances(2, 11200, 3, seed=83)
     res = {}
-    for batched in (True, False):
+    for hip in (True, False):
         m = TrainableCRN(**FULL400)
         m.load_state_dict(sd)
-        m = m.cuda().use_hip_kernels(True)
-        m.batch_segments = batched
+        m = m.cuda().use_hip_kernels(hip)
         x = torch.from_numpy(mix).cuda()
         y1 = m.realtime_process_train(x[..., :6400])
-        y2 = m.realtime_process_train(x[..., 6400:], flag=True)
+        y2 = m.realtime_process_train(x[..., 6400:].contiguous(), flag=True)
         loss = (y1 ** 2).mean() + (y2 * torch.from_numpy(clean[:, :y2.shape[-1]]).cuda()).mean()
         loss.backward()
-        res[batched] = (y1.detach().cpu(), y2.detach().cpu(), torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()]).cpu())
-    assert _rel(res[True][0], res[False][0]) < 1e-6 and _rel(res[True][1], res[False][1]) < 1e-6
-    assert _rel(res[True][2], res[False][2]) < 5e-5  # weight gradients summed over all segments at once: fp32 summation order
+        res[hip] = (y1.detach().cpu(), y2.detach().cpu(), torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()]).cpu())
+    assert _rel(res[True][0], res[False][0]) < 1e-5 and _rel(res[True][1], res[False][1]) < 1e-5
+    assert _rel(res[True][2], res[False][2]) < 1e-4
 
 
 @pytest.mark.parametrize("pre_p", ["0", "1"])

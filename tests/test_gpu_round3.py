@@ -119,3 +119,249 @@ def test_persistent_gru_is_deterministic_and_batch_independent():
     K.pseq_check()
     assert torch.equal(o1, o2) and torch.equal(h1, h2)
     assert _rel(o1[5:9], o4) < 1e-6 and _rel(h1[5:9], h4) < 1e-6
+
+
+# ---- the norm / pointwise / signal kernels of the training step, forward and backward, vs torch autograd --------------------
+def _gln_ref(a, w, b):
+    dims = tuple(range(1, a.dim()))
+    mean = a.mean(dims, keepdim=True)
+    var = ((a - mean) ** 2).mean(dims, keepdim=True)
+    return (a - mean) / (torch.sqrt(var + 1e-8) + 1e-8) * w + b
+
+
+@pytest.mark.parametrize("S,C,T,Fi,Fo,act", [(5, 16, 21, 101, 101, 1), (3, 64, 21, 25, 26, 1), (4, 8, 7, 13, 13, 0), (2, 2, 21, 201, 201, 2)])
+def test_fused_gln_channel_mode_vs_autograd(S, C, T, Fi, Fo, act):
+    """k_tgln_fwd / k_tgln_bwd_c: y = pad(gLN(act(x))) (CRN.py:135-149, 389-392) and its gradients w.r.t. the pre-activation x,
+    the affine pair and the producing convolution's bias (= per-channel sum of dx)."""
+    from speech_enhancement_mi_amd import train_net as N
+    torch.manual_seed(C + Fi)
+    x = torch.randn(S, C, T, Fi, device="cuda")
+    w, b = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    y = torch.empty(S, C, T, Fo, device="cuda")
+    st = N.gln_fwd(x, (C * T * Fi, T * Fi, Fi), N._p(y), (C * T * Fo, T * Fo, Fo), w, b, S, C, T, Fi, Fo, 0, act)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    actf = {0: lambda v: v, 1: torch.relu, 2: torch.nn.functional.elu}[act]
+    yr = torch.nn.functional.pad(_gln_ref(actf(xr), wr.view(1, C, 1, 1), br.view(1, C, 1, 1)), (0, Fo - Fi))
+    assert _rel(y, yr) < 1e-5
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    dx, dw, db, dpre = N.gln_bwd(N._p(gy), (C * T * Fo, T * Fo, Fo), x, (C * T * Fi, T * Fi, Fi), w, st, S, C, T, Fi, 0, act)
+    assert _rel(dx, xr.grad) < 2e-5 and _rel(dw, wr.grad) < 2e-5 and _rel(db, br.grad) < 2e-5
+    assert _rel(dpre, xr.grad.sum((0, 2, 3))) < 2e-4
+
+
+def test_fused_gln_last_mode_vs_autograd():
+    """k_tgln_bwd_d: the norm after fc_output_layer (GlobalLayerNorm(last=True), CRN.py:127-129, 274-276): input [S][T][D] rows
+    of the dense layer, output re-laid-out to [S][C][T][F], affine per feature d = c * F + f."""
+    from speech_enhancement_mi_amd import train_net as N
+    torch.manual_seed(9)
+    S, C, T, F = 6, 128, 21, 13
+    D = C * F
+    o = torch.randn(S * T, D, device="cuda")
+    w, b = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+    y = torch.empty(S, C, T, F, device="cuda")
+    st = N.gln_fwd(o, (T * D, F, D), N._p(y), (C * T * F, T * F, F), w, b, S, C, T, F, F, 1, 1)
+    orr, wr, br = (t.detach().clone().requires_grad_(True) for t in (o, w, b))
+    yr = _gln_ref(torch.relu(orr.view(S, 1, T, D)), wr.view(1, 1, 1, D), br.view(1, 1, 1, D)).view(S, T, C, F).permute(0, 2, 1, 3)
+    assert _rel(y, yr) < 1e-5
+    gy = torch.randn(S, C, T, F, device="cuda")
+    yr.backward(gy)
+    dx, dw, db, dpre = N.gln_bwd(N._p(gy), (C * T * F, T * F, F), o, (T * D, F, D), w, st, S, C, T, F, 1, 1)
+    assert dx.shape == o.shape
+    assert _rel(dx, orr.grad) < 2e-5 and _rel(dw, wr.grad) < 2e-5 and _rel(db, br.grad) < 2e-5
+    assert _rel(dpre, orr.grad.view(S * T, D).sum(0)) < 2e-4
+
+
+def test_fused_skip_gate_vs_autograd():
+    """k_tskip_fwd / _bwd: out = m * relu(u) + (1 - m) * z, m = sigmoid(gLN(v)) (CRN.py:393-396) with u, v the two halves of the
+    stacked 1x1 convolution output."""
+    from speech_enhancement_mi_amd import train_ops as K
+    torch.manual_seed(4)
+    S, Co, T, F = 5, 32, 21, 51
+    uv = torch.randn(S, 2 * Co, T, F, device="cuda")
+    z = torch.randn(S, Co, T, F, device="cuda")
+    nw, nb = torch.randn(Co, device="cuda"), torch.randn(Co, device="cuda")
+    out, st = torch.empty_like(z), torch.empty(S, 2, device="cuda")
+    lib = K._lib()
+    p = lambda t: t.data_ptr()
+    K._chk(lib.se_train_skip_fwd(p(uv), p(z), p(nw), p(nb), p(out), p(st), S, Co, T, F, 1, 0, K._st()))
+    uvr, zr, nwr, nbr = (t.detach().clone().requires_grad_(True) for t in (uv, z, nw, nb))
+    m = torch.sigmoid(_gln_ref(uvr[:, Co:], nwr.view(1, Co, 1, 1), nbr.view(1, Co, 1, 1)))
+    outr = m * torch.relu(uvr[:, :Co]) + (1 - m) * zr
+    assert _rel(out, outr) < 1e-5
+    g = torch.randn_like(outr)
+    outr.backward(g)
+    duv, dz = torch.empty_like(uv), torch.empty_like(z)
+    pw, pb, pbias = torch.empty(S, Co, device="cuda"), torch.empty(S, Co, device="cuda"), torch.empty(S, 2 * Co, device="cuda")
+    K._chk(lib.se_train_skip_bwd(p(g), p(uv), p(z), p(nw), p(nb), p(st), p(duv), p(dz), p(pw), p(pb), p(pbias), S, Co, T, F, 1, 0, K._st()))
+    assert _rel(duv, uvr.grad) < 2e-5 and _rel(dz, zr.grad) < 2e-5
+    assert _rel(pw.sum(0), nwr.grad) < 2e-5 and _rel(pb.sum(0), nbr.grad) < 2e-5
+    assert _rel(pbias.sum(0), uvr.grad.sum((0, 2, 3))) < 2e-4
+
+
+@pytest.mark.parametrize("n_fft,flag", [(400, False), (512, False), (400, True)])
+def test_fused_signal_chain_vs_torch_autograd(n_fft, flag):
+    """se_sig_stft over all segments == utility.padding/segmentation + torch.stft; mask -> se_sig_istft -> over_add forward against
+    torch ops, and the hand-written adjoint chain (over_add^T / envelope -> STFT -> irfft weights -> complex multiply^T ->
+    decompress') against torch autograd through torch.istft."""
+    import ctypes as C
+    from speech_enhancement_mi_amd import train_net as N
+    from speech_enhancement_mi_amd import train_ops as K
+    from speech_enhancement_mi_amd.training import TrainableCRN
+    torch.manual_seed(n_fft)
+    cfg = dict(TINY, n_fft=n_fft, num_freqs=n_fft // 2 + 1)
+    m = TrainableCRN(**cfg).cuda()
+    B, M, L = 2, 3, 7000
+    Ks, P, T, F = 3200, 1600, 21, n_fft // 2 + 1
+    mix, _ = synth.synth_utterances(B, L, M, seed=5)
+    x = _cuda(mix)
+    lib = K._lib()
+    sig = N._sig(x.device, n_fft, 400, 160, Ks)
+    Lp = L if flag else L + P
+    gap = Ks - (P + Lp % Ks) % Ks
+    Nseg = 2 * (Lp + gap + P) // Ks
+    S = Nseg * B
+    spec = torch.empty(Nseg, B * M, T, F, 2, device="cuda")
+    K._chk(lib.se_sig_stft(sig, x.data_ptr(), B, M, L, -P if flag else -2 * P, P, Nseg, spec.data_ptr(), K._st()))
+    xt = x if flag else torch.nn.functional.pad(x, (P, 0))
+    seg, gap_r = m._segment(xt)                      # [B, M, N, K]
+    X = m._stft(seg)                                 # [B, M, N, F, T] complex
+    assert gap_r == gap and X.shape[2] == Nseg
+    Xr = torch.view_as_real(X.permute(2, 0, 1, 4, 3).contiguous()).reshape(Nseg, B * M, T, F, 2)
+    assert _rel(spec, Xr) < 2e-6
+    # mask input -> prediction
+    xm = (torch.randn(S, 2, T, F, device="cuda") * 4).requires_grad_(True)   # some values beyond the +-9.9 clamp
+    Y = torch.empty(S, T, F, 2, device="cuda")
+    K._chk(lib.se_train_mask_fwd(xm.data_ptr(), spec.data_ptr(), Y.data_ptr(), S, M, T, F, K._st()))
+    yseg = torch.empty(S, Ks, device="cuda")
+    K._chk(lib.se_sig_istft(sig, Y.data_ptr(), S, yseg.data_ptr(), K._st()))
+    skip = 0 if flag else P
+    pred = torch.empty(B, L, device="cuda")
+    K._chk(lib.se_train_ola_fwd(sig, yseg.data_ptr(), pred.data_ptr(), B, L, skip, K._st()))
+    # torch reference of the same chain
+    X0 = X[:, 0].permute(1, 0, 3, 2)                 # [N, B, T, F]
+    mm = xm.view(Nseg, B, 2, T, F).clamp(-9.9, 9.9)
+    mm = -10.0 * torch.log((10.0 - mm) / (10.0 + mm))
+    Yr = torch.complex(mm[:, :, 0] * X0.real - mm[:, :, 1] * X0.imag, mm[:, :, 1] * X0.real + mm[:, :, 0] * X0.imag)
+    ysr = m._istft(Yr.permute(1, 0, 3, 2))           # [B, N, K]
+    s1 = ysr[:, 0::2].reshape(B, -1)[:, P:]
+    s2 = ysr[:, 1::2].reshape(B, -1)[:, :-P]
+    outr = ((s1 + s2) / 2)[:, :-gap]
+    outr = outr if flag else outr[:, P:]
+    assert outr.shape == pred.shape and _rel(pred, outr) < 2e-5
+    g = torch.randn_like(outr)
+    outr.backward(g)
+    gseg = torch.empty(S, Ks, device="cuda")
+    K._chk(lib.se_train_ola_bwd(sig, g.data_ptr(), gseg.data_ptr(), B, Nseg, L, skip, K._st()))
+    dY = torch.empty(S, T, F, 2, device="cuda")
+    K._chk(lib.se_sig_stft(sig, gseg.data_ptr(), S, 1, Ks, 0, 0, 1, dY.data_ptr(), K._st()))
+    dxm = torch.empty(S, 2, T, F, device="cuda")
+    K._chk(lib.se_train_mask_bwd(dY.data_ptr(), xm.data_ptr(), spec.data_ptr(), dxm.data_ptr(), S, M, T, F, n_fft, K._st()))
+    assert _rel(dxm, xm.grad) < 5e-5
+
+
+def test_fused_conv1x1_and_deterministic_wgrad():
+    """kind 3 (1x1 convolution on [S][C][T][F]) forward, its input gradient (transposed weights), the deterministic weight
+    gradient, and bit-reproducibility of the deterministic reductions."""
+    from speech_enhancement_mi_amd import train_net as N
+    torch.manual_seed(2)
+    S, Ci, Co, T, F = 7, 32, 64, 21, 51
+    x = torch.randn(S, Ci, T, F, device="cuda")
+    w = torch.randn(Co, Ci, device="cuda") * 0.2
+    b = torch.randn(Co, device="cuda")
+    y = torch.empty(S, Co, T, F, device="cuda")
+    N.conv_w(3, N._p(x), None, w, Ci, 1, b, y, S, Ci, Co, T, F, F, 0)
+    yr = torch.einsum("oc,sctf->sotf", w, x) + b.view(1, Co, 1, 1)
+    assert _rel(y, yr) < 1e-5
+    g = torch.randn_like(y)
+    dx = torch.empty_like(x)
+    N.conv_w(3, N._p(g), None, w, 1, Ci, torch.zeros(Ci, device="cuda"), dx, S, Co, Ci, T, F, F, 0)
+    assert _rel(dx, torch.einsum("oc,sotf->sctf", w, g)) < 1e-5
+    dw1 = N.wgrad(g, x, None, S, Co, Ci, T, F, F, 0, 1).view(Co, Ci)
+    dw2 = N.wgrad(g, x, None, S, Co, Ci, T, F, F, 0, 1).view(Co, Ci)
+    assert torch.equal(dw1, dw2)
+    assert _rel(dw1, torch.einsum("sotf,sctf->oc", g, x)) < 1e-5
+    a, bm = torch.randn(3000, 96, device="cuda"), torch.randn(3000, 40, device="cuda")
+    t1, t2 = N.gemm_tn(a, bm), N.gemm_tn(a, bm)
+    assert torch.equal(t1, t2) and _rel(t1, a.t() @ bm) < 1e-5
+    assert _rel(N.colsum_tall(a), a.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("utts,seconds,accum", [(8, 3.0, 2), (32, 0.6, 1)])
+def test_fused_train_step_at_bench_shape_vs_torch_autograd(utts, seconds, accum):
+    """BASELINE config 4 at the shape bench.py runs (8 x 3 s, full loss, accumulation 2) and at 32 utterances per micro-batch
+    (the two-row-tile persistent GRU).  (a) full loss: loss value and flat gradient of the fused kernels against torch autograd
+    (fp32) on the same GPU; (b) where the rounding floor of that comparison lies: with a plain MSE loss both fp32 paths are
+    compared against torch autograd in FLOAT64 - the fused kernels must be as close to it as torch's own fp32 kernels are;
+    (c) the fused step is bit-reproducible (no atomics)."""
+    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of(FULL400), seed=2).items()}
+    mix, clean = synth.synth_utterances(utts, int(seconds * 16000), 3, seed=85)
+    x, c = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
+
+    def hip_stft(seg):
+        """The torch-autograd comparator is fed the SAME fp32 spectrum as the kernels (se_sig_stft): the reference's phase feature
+        arctan(im / (re + 1e-8)) (CRN.py:464) jumps by pi where re changes sign, and two correct fp32 FFTs (or fp32 vs fp64) land on
+        different sides of re = 0 for about one bin in a million (measured: bin 124 of one frame at this shape, re = -1.2e-7 vs
+        +2.3e-7 at a frame maximum of 17) - a property of the feature, not of either implementation."""
+        from speech_enhancement_mi_amd import train_net as N, train_ops as K
+        rows = seg.reshape(-1, seg.shape[-1]).float().contiguous()
+        spec = torch.empty(rows.shape[0], 21, 201, 2, device="cuda")
+        K._chk(K._lib().se_sig_stft(N._sig(rows.device, 400, 400, 160, 3200), rows.data_ptr(), rows.shape[0], 1, 3200, 0, 0, 1, spec.data_ptr(), K._st()))
+        X = torch.view_as_complex(spec).permute(0, 2, 1).reshape(*seg.shape[:-1], 201, 21)
+        return X.to(torch.complex128 if seg.dtype == torch.float64 else torch.complex64)
+
+    def run(hip, loss_kind, dtype=torch.float32):
+        m = TrainableCRN(**FULL400)
+        m.load_state_dict(sd)
+        m = m.cuda().to(dtype).use_hip_kernels(hip)
+        if not hip:
+            m._stft = hip_stft
+        bucket = None if dtype != torch.float32 else FlatBucket(list(m.parameters()))
+        total = 0.0
+        for xm, cm in zip(x.to(dtype).chunk(accum), c.to(dtype).chunk(accum)):
+            pred = m.realtime_process_train(xm)
+            if loss_kind == "full":
+                lens = torch.full((xm.shape[0],), xm.shape[-1], dtype=torch.int64, device="cuda")
+                loss = m.compute_loss(cm, pred, lens)[0] / accum
+            else:
+                loss = ((pred - cm) ** 2).mean() * (100.0 / accum)
+            loss.backward()
+            total += float(loss.detach())
+        flat = bucket.flat if bucket is not None else torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
+        return total, flat.detach().clone()
+
+    l_t, g_t = run(False, "full")
+    l_h, g_h = run(True, "full")
+    l_h2, g_h2 = run(True, "full")
+    assert abs(l_h - l_t) < 1e-4 * max(1.0, abs(l_t))
+    assert _rel(g_h, g_t) < 3e-3, _rel(g_h, g_t)
+    assert l_h == l_h2 and torch.equal(g_h, g_h2)
+    _, g64 = run(False, "mse", torch.float64)
+    _, gt32 = run(False, "mse")
+    _, gh32 = run(True, "mse")
+    e_t, e_h = _rel(gt32.double(), g64), _rel(gh32.double(), g64)
+    print(f"flat-gradient error vs float64 autograd: torch fp32 {e_t:.2e}, fused kernels {e_h:.2e}")
+    assert e_h < max(2.0 * e_t, 5e-5), (e_h, e_t)
+
+
+def test_merged_microbatches_give_the_accumulated_gradient():
+    """train_step(accum=2): one shared forward/backward sweep over both micro-batches with the loss formed per micro-batch gives
+    the gradient (and the parameters after Adam) of the sequential accumulation loop to fp32 summation order."""
+    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN, train_step
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of(FULL400), seed=4).items()}
+    mix, clean = synth.synth_utterances(4, 9600, 3, seed=87)
+    x, c = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
+    lens = torch.tensor([9600, 9000, 9600, 7000], device="cuda")
+    res = {}
+    for merge in (True, False):
+        m = TrainableCRN(**FULL400)
+        m.load_state_dict(sd)
+        m = m.cuda().use_hip_kernels(True)
+        bucket = FlatBucket(list(m.parameters()))
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+        l = train_step(m, bucket, opt, x, c, lens, accum=2, loss="full", merge=merge)
+        res[merge] = (l, bucket.flat.clone(), torch.cat([p.detach().flatten() for p in m.parameters()]))
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1.0, abs(res[False][0]))
+    assert _rel(res[True][1], res[False][1]) < 2e-5
+    assert _rel(res[True][2], res[False][2]) < 1e-6
