@@ -139,6 +139,8 @@ typedef struct {
     int32_t sb_neighbors, fb_neighbors; /* sb_num_neighbors (15), fb_num_neighbors (0: the only supported value) */
     int32_t look_ahead;                 /* 0 */
     int32_t n_fft, win, hop, segment_length;
+    int32_t precision;                  /* ABI 4: 0 = fp32-accurate LSTM contractions (6-term split-bf16 MFMA); 2 = 3-term split-bf16
+                                           ("bf16x3": inside the 1e-4 / 0.02 dB parity bar, half the matrix work); 1 is not offered */
 } fsn_config;
 
 typedef struct fsn_engine fsn_engine;

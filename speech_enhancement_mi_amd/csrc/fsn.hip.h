@@ -122,9 +122,11 @@ struct LstmStepArgs {
     int R, H;
 };
 
+// PL = operand planes: 3 = fp32-accurate (six products), 2 = "bf16x3" (hi, mid: three products, fsn_config.precision = 2)
+template <int PL>
 __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
-    __shared__ __align__(16) __bf16 Ap[3][kGemmBM * kXLd];
-    __shared__ __align__(16) __bf16 Wl[3][kGemmBN * kXLd];
+    __shared__ __align__(16) __bf16 Ap[PL][kGemmBM * kXLd];
+    __shared__ __align__(16) __bf16 Wl[PL][kGemmBN * kXLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * kGemmBM, h0 = blockIdx.x * 32;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
         for (int r = 0; r < 16; r++) acc[g][r] = 0.0f;
 
     f32x4 qa[4];
-    uint4 qw[6];
+    uint4 qw[2 * PL];
     auto issue = [&](int ck) {
         const int k0 = ck * kGemmKC;
         const bool from_x = k0 < a.K1p;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
             qa[it] = *reinterpret_cast<const f32x4 *>(src + (long)row * ld + k);
         }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
+        for (int it = 0; it < 2 * PL; it++) {
             const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
             const int hid = min(h0 + (r & 31), H - 1), wrow = (r >> 5) * H + hid;
             qw[it] = *reinterpret_cast<const uint4 *>(a.Wp + ((long)plane * 4 * H + wrow) * Kt + k0 + q);
@@ -176,10 +178,10 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
             }
             *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
             *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
-            *reinterpret_cast<bf16x4 *>(&Ap[2][r * kXLd + kq]) = l;
+            if (PL > 2) *reinterpret_cast<bf16x4 *>(&Ap[PL - 1][r * kXLd + kq]) = l;
         }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
+        for (int it = 0; it < 2 * PL; it++) {
             const int seg = tid + it * 256, plane = seg >> 9, w = seg & 511, r = w >> 2, q = (w & 3) * 8;
             const bool ok = h0 + (r & 31) < H;
             *reinterpret_cast<uint4 *>(&Wl[plane][r * kXLd + q]) = ok ? qw[it] : make_uint4(0, 0, 0, 0);
@@ -188,18 +190,20 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
         if (ck + 1 < nck) issue(ck + 1);
 #pragma unroll
         for (int ks = 0; ks < kGemmKC; ks += 16) {
-            bf16x8 fa[3];
+            bf16x8 fa[PL];
 #pragma unroll
-            for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const bf16x8 *>(&Ap[p][(wave * 32 + l31) * kXLd + ks + half * 8]);
+            for (int p = 0; p < PL; p++) fa[p] = *reinterpret_cast<const bf16x8 *>(&Ap[p][(wave * 32 + l31) * kXLd + ks + half * 8]);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                bf16x8 fb[3];
+                bf16x8 fb[PL];
 #pragma unroll
-                for (int p = 0; p < 3; p++) fb[p] = *reinterpret_cast<const bf16x8 *>(&Wl[p][(g * 32 + l31) * kXLd + ks + half * 8]);
+                for (int p = 0; p < PL; p++) fb[p] = *reinterpret_cast<const bf16x8 *>(&Wl[p][(g * 32 + l31) * kXLd + ks + half * 8]);
                 f32x16 c = acc[g];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], c, 0, 0, 0);
+                if (PL > 2) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[PL - 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PL - 1], fb[0], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], c, 0, 0, 0);

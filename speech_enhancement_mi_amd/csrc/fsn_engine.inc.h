@@ -118,7 +118,8 @@ int fsn_prepare(fsn_engine *e) {
 int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, long ldx, int K1, int K1p, int R, float *hseq, long ldseq, hipStream_t st) {
     const int hc = m.hcur[l];
     LstmStepArgs a{x, ldx, K1, K1p, m.h[l][hc].p, reinterpret_cast<const __bf16 *>(m.Wp[l].p), m.bias[l].p, m.c[l].p, m.h[l][hc ^ 1].p, hseq, ldseq, R, m.H};
-    hipLaunchKernelGGL(k_lstm_step_x6, dim3((m.H + 31) / 32, (R + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, a);
+    if (e->c.precision == 2) hipLaunchKernelGGL(k_lstm_step_x6<2>, dim3((m.H + 31) / 32, (R + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_lstm_step_x6<3>, dim3((m.H + 31) / 32, (R + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, a);
     m.hcur[l] = hc ^ 1;
     return 0;
 }
@@ -226,6 +227,7 @@ int fsn_create(const fsn_config *cfg, int device, fsn_engine **out) {
     if (cfg->num_layers < 1 || cfg->num_layers > 4) return ffail(nullptr, SE_ERR_ARG, "num_layers %d out of range", cfg->num_layers);
     if (cfg->fb_hidden % 8 || cfg->sb_hidden % 8 || cfg->fb_hidden <= 0 || cfg->sb_hidden <= 0) return ffail(nullptr, SE_ERR_ARG, "hidden sizes must be positive multiples of 8");
     if ((2 * cfg->sb_neighbors + 2) % 4) return ffail(nullptr, SE_ERR_ARG, "sub-band input width 2*sb_num_neighbors+2 must be a multiple of 4");
+    if (cfg->precision != 0 && cfg->precision != 2) return ffail(nullptr, SE_ERR_ARG, "fsn precision %d unknown (0 fp32-accurate, 2 bf16x3)", cfg->precision);
     // STFT tables / launchers: borrow a CRN engine object configured with the same STFT geometry
     se_config sc{};
     sc.num_levels = 4; for (int i = 0; i < 4; i++) sc.channels[i] = 8;

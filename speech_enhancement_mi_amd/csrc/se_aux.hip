@@ -32,9 +32,13 @@ void launch_k_fsn_mask(dim3 grid, hipStream_t st, const FsnMaskArgs &a) { hipLau
 
 void aux_set_fft_lds(int stft_bytes, int istft_bytes) {
     // engines / signal handles of different STFT sizes share the kernels: the opt-in only ever grows
+    // (a geometry whose segment does not fit the 160 KB of LDS - FullSubNet's train=True engine with one N*T-frame "segment" -
+    // never launches these kernels and must not poison the opt-in of the others)
     static int cur_stft = 0, cur_istft = 0;
-    stft_bytes = cur_stft = stft_bytes > cur_stft ? stft_bytes : cur_stft;
-    istft_bytes = cur_istft = istft_bytes > cur_istft ? istft_bytes : cur_istft;
+    const int kMaxLds = 160 * 1024;
+    if (stft_bytes <= kMaxLds && stft_bytes > cur_stft) cur_stft = stft_bytes;
+    if (istft_bytes <= kMaxLds && istft_bytes > cur_istft) cur_istft = istft_bytes;
+    stft_bytes = cur_stft; istft_bytes = cur_istft;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft), hipFuncAttributeMaxDynamicSharedMemorySize, stft_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft), hipFuncAttributeMaxDynamicSharedMemorySize, istft_bytes);
 }

@@ -45,7 +45,8 @@ class TrainConvLayout(C.Structure):  # se_train_conv_layout
 class FsnConfig(C.Structure):
     _fields_ = [("num_freqs", C.c_int32), ("num_mics", C.c_int32), ("fb_hidden", C.c_int32), ("sb_hidden", C.c_int32),
                 ("num_layers", C.c_int32), ("sb_neighbors", C.c_int32), ("fb_neighbors", C.c_int32), ("look_ahead", C.c_int32),
-                ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32), ("segment_length", C.c_int32)]
+                ("n_fft", C.c_int32), ("win", C.c_int32), ("hop", C.c_int32), ("segment_length", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 _lib = None
@@ -310,11 +311,11 @@ class FsnEngine:
     """RAII wrapper over one fsn_engine handle (FullSubNet, fullsubnet.py:685-961)."""
 
     def __init__(self, num_freqs, num_mics, fb_hidden, sb_hidden, num_layers=2, sb_neighbors=15, fb_neighbors=0, look_ahead=0,
-                 sample_rate=16000, segment_length=3200, win_length=25, hop_length=10, n_fft=400, device=0):
+                 sample_rate=16000, segment_length=3200, win_length=25, hop_length=10, n_fft=400, device=0, precision=0):
         self.lib = load_library()
         cfg = FsnConfig(int(num_freqs), int(num_mics), int(fb_hidden), int(sb_hidden), int(num_layers), int(sb_neighbors),
                         int(fb_neighbors), int(look_ahead), int(n_fft), int(round(sample_rate / 1000.0 * win_length)),
-                        int(round(sample_rate / 1000.0 * hop_length)), int(segment_length))
+                        int(round(sample_rate / 1000.0 * hop_length)), int(segment_length), int(precision))
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.fsn_create(C.byref(cfg), int(device), C.byref(h))
