@@ -308,16 +308,18 @@ def timed_region(fn, steps, warmup, world, backend):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
-def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant=0, data="fixed"):
+def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_model=None):
     """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
     all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
     micro-batches, grad accumulation 2 like config.yaml:99), all-reduce, clip, Adam.  value = utterances/s over all ranks."""
     import torch
     from speech_enhancement_mi_amd import synth
-    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN, train_step
+    train_model = train_model or args.train_model
+    from speech_enhancement_mi_amd.training import FlatBucket, TrainableCRN, TrainableCRNELU, train_step
     cfg = crn_cfg(400)  # the reference's training geometry (config.yaml:205-217)
-    model = TrainableCRN(**cfg)
-    spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3)
+    variant = 1 if train_model == "crn_elu" else 0
+    model = (TrainableCRNELU if variant else TrainableCRN)(**cfg)
+    spec = synth.crn_param_spec(cfg["num_channels"], cfg["num_freqs"], cfg["hidden"], cfg["num_layers"], 3, 3, variant=variant)
     sd = synth.make_state_dict(spec, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.cuda()
@@ -354,10 +356,10 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant
                              "priced against the fp32 matrix peak; k_conv_igemm = conv / deconv forward AND their input gradients",
                         kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=v["flops"] / max(v["ms"], 1e-9) / 1e9) for k, v in prof.items()},
                         step_ms_profiled=sum(v["ms"] for v in prof.values()))
-    result = dict(metric="DP training utterances/sec (TemporalCRN, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
+    result = dict(metric=f"DP training utterances/sec ({'CRN_ELU' if variant else 'TemporalCRN'}, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
                   steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, higher_is_better=True, scaling="weak",
                   vs_baseline=None, dtype="f32", data="synthetic",
-                  config=dict(workload=f"TemporalCRN 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
+                  config=dict(workload=f"{'CRN_ELU (CRN_ELU.py, the model train.py:16 trains)' if variant else 'TemporalCRN (CRN.py)'} 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
                                        f"loss = {args.train_loss}, accum {args.accum} ({'micro-batches share one forward/backward sweep, loss formed per micro-batch: same gradient' if not args.no_merge else 'micro-batches run one after the other'}), "
                                        f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
@@ -368,8 +370,8 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, variant
     return result
 
 
-def train_line(args, rank, local_rank):
-    r = train_measure(args, rank, local_rank, 1, "none", steps=3, warmup=2)
+def train_line(args, rank, local_rank, train_model="crn"):
+    r = train_measure(args, rank, local_rank, 1, "none", steps=3, warmup=2, train_model=train_model)
     return {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} | dict(workload=r["config"]["workload"])
 
 
@@ -545,6 +547,7 @@ def secondary_lines(args, rank, local_rank):
     leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, f16 (the config's named dtype; outside the parity bar)", crn_leg("student", 1024, "f16", 400))
     leg("CRN_ELU (the variant train.py trains) streaming, batch 256, f32", crn_leg("crn_elu", 256, "f32", 400))
     leg("BASELINE configs[3]: TemporalCRN training step, 8 x 3 s utterances per GPU, accum 2, full loss", lambda: train_line(args, rank, local_rank))
+    leg("CRN_ELU training step (the model train.py:16 trains), 8 x 3 s utterances per GPU, accum 2, full loss", lambda: train_line(args, rank, local_rank, "crn_elu"))
     return out
 
 
@@ -594,6 +597,7 @@ def parse_args(argv=None):
                     help="--mode train: hip = hand-written forward/backward kernels for conv / transposed conv / GRU (default); torch = autograd checker path")
     ap.add_argument("--train-loss", choices=["full", "sisnr"], default="full",
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
+    ap.add_argument("--train-model", choices=["crn", "crn_elu"], default="crn", help="--mode train: CRN.py (BASELINE configs[3]) or CRN_ELU.py (what train.py imports)")
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -266,13 +266,27 @@ int se_train_skip_fwd(const float *uv, const float *z, const float *nw, const fl
 int se_train_skip_bwd(const float *dout, const float *uv, const float *z, const float *nw, const float *nb, const float *stats, float *duv, float *dz,
                       float *dnw_part, float *dnb_part, float *dbias_part, int S, int Co, int T, int F, int act, int eps_mode, void *stream);
 int se_train_add(float *dst, const float *src, int64_t n, void *stream);
+int se_train_add3(float *dst, const float *a, const float *b, int64_t n, void *stream);   /* dst = a + b */
+/* CRN_ELU deltas (CRN_ELU.py:194-252, 335-340): gated 1x1 pair + norm: tg [S][2C][T][F] = (conv_trans | conv_gated)(a);
+ * y = gLN(t * sigmoid(g)); bwd -> dtg and slabs dw_part / db_part [S][C], dbias_part [S][2C].  se_train_elu_bwd: in place
+ * da -> dy through a = ELU(y) from the saved activation, + the [S][C] slab of per-channel sums.  se_train_pre5: the 5-channel 5x5
+ * frequency-dilated pre-conv blocks (C <= 8, vector ALU): mode 0 forward (act 2 stores ELU), 1 input gradient, 2 weight-gradient
+ * slab [S][C*C*25]. */
+int se_train_gate_fwd(const float *tg, const float *w, const float *b, float *y, int64_t yS, int64_t yC, int64_t yT, float *stats, int S, int C, int T, int F,
+                      int eps_mode, void *stream);
+int se_train_gate_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const float *tg, const float *w, const float *stats, float *dtg, float *dw_part,
+                      float *db_part, float *dbias_part, int S, int C, int T, int F, int eps_mode, void *stream);
+int se_train_elu_bwd(float *da, const float *act, float *dpre_part, int S, int C, int T, int F, void *stream);
+int se_train_pre5(int mode, const float *x, const float *xprev, const float *w, const float *bias, const float *dy, float *out, int S, int C, int T, int F,
+                  int fd, int act, void *stream);
 /* h_{s-1} rows for the recurrent weight gradient (row addressing as se_train_gru_pseq_*) */
 int se_train_gru_hprev(const float *out, const float *h0, float *hp, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, void *stream);
 /* se_train_conv with the weights in their checkpoint layout (element (row, col, kf, kt) at w[row*sCo + col*sCi + kf*3 + kt]); kind 3 =
  * 1x1 convolution.  ws: se_train_conv_ws_floats() floats of scratch for the staged arrangement. */
 int se_train_conv_ws_floats(int kind, int Ci, int Co, int T, int Fi, int Fy, int dil);
 int se_train_conv_w(int kind, const float *x, const float *xprev, const float *w, int64_t sCo, int64_t sCi, const float *bias, float *y, float *ws,
-                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, void *stream);
+                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, int Cy, int cy0, void *stream);
+                    /* Cy > 0: y has Cy channels per stream and this launch writes channels [cy0, cy0 + Co) */
 /* deterministic weight gradients: partial tiles per row split into ws[<= 64][...] (fold with se_train_colsum); ntap 15 or 1 */
 int se_train_conv_wgrad_det(const float *G, const float *S, const float *Sprev, float *ws, int *nsplit_out, int B, int Ca, int Cb, int T, int Fm,
                             int Fs, int dil, int ntap, void *stream);

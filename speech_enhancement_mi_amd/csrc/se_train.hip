@@ -266,6 +266,60 @@ int se_train_skip_bwd(const float *dout, const float *uv, const float *z, const 
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
+int se_train_gate_fwd(const float *tg, const float *w, const float *b, float *y, int64_t yS, int64_t yC, int64_t yT, float *stats, int S, int C, int T, int F,
+                      int eps_mode, void *stream) {
+    if (!tg || !w || !b || !y || !stats || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TGateArgs a{};
+    a.tg = tg; a.w = w; a.b = b; a.y = y; a.stats = stats; a.C = C; a.T = T; a.F = F; a.eps_mode = eps_mode; a.yS = yS; a.yC = yC; a.yT = yT;
+    hipLaunchKernelGGL(se::k_tgate_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_gate_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const float *tg, const float *w, const float *stats, float *dtg, float *dw_part,
+                      float *db_part, float *dbias_part, int S, int C, int T, int F, int eps_mode, void *stream) {
+    if (!dy || !tg || !w || !stats || !dtg || !dw_part || !db_part || !dbias_part || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    se::TGateArgs a{};
+    a.dy = dy; a.tg = tg; a.w = w; a.stats = const_cast<float *>(stats); a.dtg = dtg; a.dw_part = dw_part; a.db_part = db_part; a.dbias_part = dbias_part;
+    a.C = C; a.T = T; a.F = F; a.eps_mode = eps_mode; a.yS = dS; a.yC = dC; a.yT = dT;
+    hipLaunchKernelGGL(se::k_tgate_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_elu_bwd(float *da, const float *act, float *dpre_part, int S, int C, int T, int F, void *stream) {
+    if (!da || !act || !dpre_part || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_telu_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), da, act, dpre_part, C, T * F);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+/* mode 0: y = act(conv5x5(x | xprev)); mode 1: dx from dy; mode 2: dw_part [S][C*C*25] from dy and x | xprev */
+int se_train_pre5(int mode, const float *x, const float *xprev, const float *w, const float *bias, const float *dy, float *out, int S, int C, int T, int F,
+                  int fd, int act, void *stream) {
+    if (!w || !out || S <= 0 || C <= 0 || C > 8 || fd <= 0) return train_fail(SE_ERR_ARG, "bad argument (C <= 8)");
+    se::TPre5Args a{};
+    a.x = x; a.xprev = xprev; a.w = w; a.bias = bias; a.dy = dy; a.C = C; a.T = T; a.F = F; a.fd = fd; a.act = act;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == 0) {
+        if (!x || !bias) return train_fail(SE_ERR_ARG, "null argument");
+        a.y = out;
+        hipLaunchKernelGGL(se::k_pre5_fwd, dim3((T * F + 255) / 256, S), dim3(256), 0, st, a);
+    } else if (mode == 1) {
+        if (!dy) return train_fail(SE_ERR_ARG, "null argument");
+        a.dx = out;
+        hipLaunchKernelGGL(se::k_pre5_dx, dim3((T * F + 255) / 256, S), dim3(256), 0, st, a);
+    } else {
+        if (!dy || !x) return train_fail(SE_ERR_ARG, "null argument");
+        a.dw_part = out;
+        hipLaunchKernelGGL(se::k_pre5_dw, dim3(C * C, S), dim3(256), 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
+int se_train_add3(float *dst, const float *a, const float *b, int64_t n, void *stream) {
+    if (!dst || !a || !b || n <= 0) return train_fail(SE_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(se::k_tadd3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, a, b, (long)n);
+    return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
+}
+
 int se_train_add(float *dst, const float *src, int64_t n, void *stream) {
     if (!dst || !src || n <= 0) return train_fail(SE_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(se::k_tadd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, (long)n);

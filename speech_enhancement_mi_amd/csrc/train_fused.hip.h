@@ -367,6 +367,217 @@ __global__ __launch_bounds__(256) void k_tola_bwd(const float *dout, const float
     g[((long)n * B + b) * K + k] = v;
 }
 
+// ---- CRN_ELU deltas (CRN_ELU.py:194-252, 335-340, 375-376) -----------------------------------------------------------------------
+// Gated 1x1 pair + norm: tg [S][2C][T][F] holds conv_trans(a) in channels [0, C) and conv_gated(a) in [C, 2C);
+// p = t * sigmoid(g); y = gLN(p) (CRN_ELU.py:240-241).  Backward: dp by the gLN formula, dt = dp * sigmoid(g), dg = dp * t * s (1 - s);
+// per-channel sums of dt / dg = the bias gradients of the pair.
+struct TGateArgs {
+    const float *tg, *dy;
+    float *y, *dtg;
+    const float *w, *b;
+    float *stats;
+    float *dw_part, *db_part, *dbias_part;  // [S][C], [S][C], [S][2C]
+    int C, T, F, eps_mode;
+    long yS, yC, yT;  // element (s, c, t, f) of y (forward) / dy (backward) at s * yS + c * yC + t * yT + f
+};
+
+__global__ __launch_bounds__(256) void k_tgate_fwd(TGateArgs a) {
+    __shared__ double red[8];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int TF = a.T * a.F, n = a.C * TF;
+    const float *t = a.tg + (long)s * 2 * n, *g = t + n;
+    double sum = 0, dummy = 0;
+    for (int e = tid; e < n; e += 256) sum += (double)(t[e] / (1.0f + expf(-g[e])));
+    t_block_sum2(sum, dummy, red);
+    const float mean = (float)(sum / n);
+    double sq = 0;
+    dummy = 0;
+    for (int e = tid; e < n; e += 256) { const float d = t[e] / (1.0f + expf(-g[e])) - mean; sq += (double)(d * d); }
+    t_block_sum2(sq, dummy, red);
+    const float var = (float)(sq / n);
+    const float inv = 1.0f / ((a.eps_mode ? sqrtf(var) : sqrtf(var + kTEps)) + kTEps);
+    if (tid == 0) { a.stats[2 * s] = mean; a.stats[2 * s + 1] = inv; }
+    float *y = a.y + (long)s * a.yS;
+    for (int e = tid; e < n; e += 256) {
+        const int c = e / TF, r = e - c * TF, tt = r / a.F, f = r - tt * a.F;
+        y[c * a.yC + tt * a.yT + f] = (t[e] / (1.0f + expf(-g[e])) - mean) * inv * a.w[c] + a.b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tgate_bwd(TGateArgs a) {
+    __shared__ double red[8];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TF = a.T * a.F, n = a.C * TF;
+    const float *t = a.tg + (long)s * 2 * n, *g = t + n;
+    const float *dy = a.dy + (long)s * a.yS;
+    float *dt = a.dtg + (long)s * 2 * n, *dg = dt + n;
+    const float mean = a.stats[2 * s], inv = a.stats[2 * s + 1];
+    double S1 = 0, S2 = 0;
+    for (int c = wave; c < a.C; c += 4) {
+        const float wc = a.w[c];
+        float pw = 0.0f, pb = 0.0f;
+        for (int r = lane; r < TF; r += 64) {
+            const int e = c * TF + r, tt = r / a.F, f = r - tt * a.F;
+            const float ph = (t[e] / (1.0f + expf(-g[e])) - mean) * inv;
+            const float d = dy[c * a.yC + tt * a.yT + f];
+            pw += d * ph; pb += d;
+        }
+        pw = t_wave_sum(pw); pb = t_wave_sum(pb);
+        if (lane == 0) {
+            a.dw_part[(long)s * a.C + c] = pw; a.db_part[(long)s * a.C + c] = pb;
+            S1 += (double)(wc * pb); S2 += (double)(wc * pw);
+        }
+    }
+    t_block_sum2(S1, S2, red);
+    const float sd = 1.0f / inv - kTEps;
+    const float m1 = (float)(S1 / n), m2 = (float)(S2 / n) / (a.eps_mode ? fmaxf(sd, 1e-30f) : sd);
+    for (int c = wave; c < a.C; c += 4) {
+        const float wc = a.w[c];
+        float pt = 0.0f, pg = 0.0f;
+        for (int r = lane; r < TF; r += 64) {
+            const int e = c * TF + r, tt = r / a.F, f = r - tt * a.F;
+            const float sg = 1.0f / (1.0f + expf(-g[e])), tv = t[e];
+            const float ph = (tv * sg - mean) * inv;
+            const float dp = inv * (dy[c * a.yC + tt * a.yT + f] * wc - m1) - ph * m2;
+            const float vt = dp * sg, vg = dp * tv * sg * (1.0f - sg);
+            dt[e] = vt; dg[e] = vg;
+            pt += vt; pg += vg;
+        }
+        pt = t_wave_sum(pt); pg = t_wave_sum(pg);
+        if (lane == 0) { a.dbias_part[(long)s * 2 * a.C + c] = pt; a.dbias_part[(long)s * 2 * a.C + a.C + c] = pg; }
+    }
+}
+
+// da -> dy through a = ELU(y), from the saved activation only: ELU'(y) = 1 (a > 0) or e^y = a + 1; also the per-channel sums of dy
+// (the producing convolution's bias gradient) as [S][C] slabs
+__global__ __launch_bounds__(256) void k_telu_bwd(float *da, const float *aact, float *dpre_part, int C, int TF) {
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float pp = 0.0f;
+        for (int r = lane; r < TF; r += 64) {
+            const long e = ((long)s * C + c) * TF + r;
+            const float av = aact[e];
+            const float v = da[e] * (av > 0.0f ? 1.0f : av + 1.0f);
+            da[e] = v;
+            pp += v;
+        }
+        pp = t_wave_sum(pp);
+        if (lane == 0) dpre_part[(long)s * C + c] = pp;
+    }
+}
+
+// The three 5-channel 5x5 pre-conv blocks (CRN_ELU.py:335-340): Conv2d(C -> C, (5,5), dilation (fd, 1), padding (2 fd, 0)) over
+// cat(buffer[4 frames], x): out[co][t][f] = b + sum w[co][ci][kf][kt] * in[ci][t + kt - 4][f + (kf - 2) fd]; rows t < 0 from xprev.
+// C <= 8: vector-ALU kernels (0.6 kMAC per position), one thread per output position.  act = 2 stores ELU(out).
+struct TPre5Args {
+    const float *x, *xprev, *w, *bias, *dy;
+    float *y, *dx, *dw_part;
+    int C, T, F, fd, act;
+};
+__global__ __launch_bounds__(256) void k_pre5_fwd(TPre5Args a) {
+    __shared__ float ws[8 * 8 * 25 + 8];
+    const int s = blockIdx.y, C = a.C, TF = a.T * a.F;
+    for (int i = threadIdx.x; i < C * C * 25; i += 256) ws[i] = a.w[i];
+    if (threadIdx.x < C) ws[8 * 8 * 25 + threadIdx.x] = a.bias[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= TF) return;
+    const int t = i / a.F, f = i - t * a.F;
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; co++) acc[co] = co < C ? ws[8 * 8 * 25 + co] : 0.0f;
+    for (int ci = 0; ci < C; ci++)
+        for (int kt = 0; kt < 5; kt++) {
+            int ts = t + kt - 4;
+            const float *src = a.x;
+            if (ts < 0) { ts += a.T; src = a.xprev; }
+            if (!src) continue;
+            const float *row = src + (((long)s * C + ci) * a.T + ts) * a.F;
+            for (int kf = 0; kf < 5; kf++) {
+                const int ff = f + (kf - 2) * a.fd;
+                if (ff < 0 || ff >= a.F) continue;
+                const float v = row[ff];
+#pragma unroll
+                for (int co = 0; co < 8; co++)
+                    if (co < C) acc[co] += ws[((co * C + ci) * 5 + kf) * 5 + kt] * v;
+            }
+        }
+#pragma unroll
+    for (int co = 0; co < 8; co++)
+        if (co < C) a.y[((long)s * C + co) * TF + i] = t_act(acc[co], a.act);
+}
+// dx[ci][t'][f'] = sum w[co][ci][kf][kt] * dy[co][t' - kt + 4][f' - (kf - 2) fd]   (rows beyond the segment contribute nothing: the
+// history is detached, CRN_ELU.py:243)
+__global__ __launch_bounds__(256) void k_pre5_dx(TPre5Args a) {
+    __shared__ float ws[8 * 8 * 25];
+    const int s = blockIdx.y, C = a.C, TF = a.T * a.F;
+    for (int i = threadIdx.x; i < C * C * 25; i += 256) ws[i] = a.w[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= TF) return;
+    const int t = i / a.F, f = i - t * a.F;
+    float acc[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ci++) acc[ci] = 0.0f;
+    for (int co = 0; co < C; co++)
+        for (int kt = 0; kt < 5; kt++) {
+            const int to = t - kt + 4;
+            if (to >= a.T) continue;
+            const float *row = a.dy + (((long)s * C + co) * a.T + to) * a.F;
+            for (int kf = 0; kf < 5; kf++) {
+                const int ff = f - (kf - 2) * a.fd;
+                if (ff < 0 || ff >= a.F) continue;
+                const float v = row[ff];
+#pragma unroll
+                for (int ci = 0; ci < 8; ci++)
+                    if (ci < C) acc[ci] += ws[((co * C + ci) * 5 + kf) * 5 + kt] * v;
+            }
+        }
+#pragma unroll
+    for (int ci = 0; ci < 8; ci++)
+        if (ci < C) a.dx[((long)s * C + ci) * TF + i] = acc[ci];
+}
+// dW[co][ci][kf][kt] partial of ONE stream: block (pair = co * C + ci, s); every thread keeps the 25 tap sums of its positions
+__global__ __launch_bounds__(256) void k_pre5_dw(TPre5Args a) {
+    __shared__ float red[4][25];
+    const int s = blockIdx.y, C = a.C, TF = a.T * a.F;
+    const int co = blockIdx.x / C, ci = blockIdx.x - co * C;
+    float acc[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) acc[k] = 0.0f;
+    const float *dyc = a.dy + ((long)s * C + co) * TF;
+    for (int i = threadIdx.x; i < TF; i += 256) {
+        const int t = i / a.F, f = i - t * a.F;
+        const float g = dyc[i];
+#pragma unroll
+        for (int kt = 0; kt < 5; kt++) {
+            int ts = t + kt - 4;
+            const float *src = a.x;
+            if (ts < 0) { ts += a.T; src = a.xprev; }
+            if (!src) continue;
+            const float *row = src + (((long)s * C + ci) * a.T + ts) * a.F;
+#pragma unroll
+            for (int kf = 0; kf < 5; kf++) {
+                const int ff = f + (kf - 2) * a.fd;
+                if (ff >= 0 && ff < a.F) acc[kf * 5 + kt] += g * row[ff];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        const float v = t_wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 25) a.dw_part[((long)s * C * C + blockIdx.x) * 25 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_tadd3(float *dst, const float *a, const float *b, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = a[i] + b[i];
+}
+
 __global__ __launch_bounds__(256) void k_tadd(float *dst, const float *src, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += src[i];

@@ -507,7 +507,7 @@ int se_train_conv_ws_floats(int kind, int Ci, int Co, int T, int Fi, int Fy, int
     return g.a.nchunk * g.a.ntap * g.a.CC * g.a.CoPad;
 }
 int se_train_conv_w(int kind, const float *x, const float *xprev, const float *w, int64_t sCo, int64_t sCi, const float *bias, float *y, float *ws,
-                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, void *stream) {
+                    int B, int Ci, int Co, int T, int Fi, int Fy, int dil, int act, int Cy, int cy0, void *stream) {
     if (!x || !w || !bias || !y || !ws || B <= 0) return tfail(SE_ERR_ARG, "null argument");
     TrainConvGeo g;
     int rc = train_conv_geometry(kind, Ci, Co, T, Fi, Fy, dil, g);
@@ -517,6 +517,10 @@ int se_train_conv_w(int kind, const float *x, const float *xprev, const float *w
     ConvArgs a = g.a;
     a.x = x; a.xprev = xprev; a.w = ws; a.bias = bias; a.y = y;
     a.act = act; a.relu_lo = 0; a.relu_hi = act ? Co : 0;
+    if (Cy > 0) {  // the Co output channels land at channels [cy0, cy0 + Co) of a tensor with Cy channels per stream
+        if (cy0 < 0 || cy0 + Co > Cy) return tfail(SE_ERR_ARG, "channel window [%d, %d) outside %d channels", cy0, cy0 + Co, Cy);
+        a.Cy = Cy; a.cy0 = cy0;
+    }
     train_conv_attributes();
     if (conv_igemm_launch(a.ntap, g.NT, a.CoPad, dim3(g.grid_x, B), g.lds, st, a))
         return tfail(SE_ERR_ARG, "no conv kernel instance for %d taps x %d tiles", a.ntap, g.NT);

@@ -47,7 +47,7 @@ def _run(name, flops, fn, *args):
 
 
 # ---- thin launch helpers ---------------------------------------------------------------------------------------------------------
-def conv_w(kind, x_ptr, xprev_ptr, w, sCo, sCi, bias, y, S, Ci, Co, T, Fi, Fy, d, act=0):
+def conv_w(kind, x_ptr, xprev_ptr, w, sCo, sCi, bias, y, S, Ci, Co, T, Fi, Fy, d, act=0, Cy=0, cy0=0):
     lib = K._lib()
     n = lib.se_train_conv_ws_floats(kind, Ci, Co, T, Fi, Fy, d)
     if n < 0:
@@ -56,7 +56,7 @@ def conv_w(kind, x_ptr, xprev_ptr, w, sCo, sCi, bias, y, S, Ci, Co, T, Fi, Fy, d
     FP = Fy if kind in (0, 3) else ((Fy + 1) // 2 if kind == 1 else Fy // 2)
     ntap = {0: 15, 1: 9, 2: 6, 3: 1}[kind]
     _run("k_conv_igemm", 2.0 * S * Co * Ci * ntap * T * FP, lib.se_train_conv_w, kind, x_ptr, xprev_ptr, _p(w), sCo, sCi, _p(bias), _p(y), _p(ws),
-         S, Ci, Co, T, Fi, Fy, d, act, K._st())
+         S, Ci, Co, T, Fi, Fy, d, act, Cy, cy0, K._st())
 
 
 def wgrad(G, Sx, Sprev_ptr, S, Ca, Cb, T, Fm, Fs, d, ntap):
@@ -132,7 +132,8 @@ def transpose(w):
 
 
 class CRNFunction(torch.autograd.Function):
-    """pred = realtime_process(mixture) for the CRN.py model (variant 0).  forward(ctx, model, mixture, flag, *params)."""
+    """pred = realtime_process(mixture) for the CRN.py (variant 0) and CRN_ELU.py (variant 1, the model train.py:16 trains) networks.
+    forward(ctx, model, mixture, flag, *params)."""
 
     @staticmethod
     def forward(ctx, model, mixture, flag, *params):
@@ -166,30 +167,68 @@ class CRNFunction(torch.autograd.Function):
 
         spec = _new(N, B * M, T, F0, 2, dev=dev)
         _run("k_stft", 0.0, lib.se_sig_stft, sig, _p(mixture), B, M, L, off0, P, N, _p(spec), st())
+        V = model._VARIANT            # 0 = CRN.py (ReLU); 1 = CRN_ELU.py (ELU, gated 1x1 pair per block, three 5x5 pre-conv blocks, atan2 phase)
+        if V not in (0, 1):
+            raise NotImplementedError("the training kernels cover CRN.py and CRN_ELU.py (the student is trained by distillation, out of scope)")
+        act = 2 if V else 1
+
+        def first_slab(t, key, idx):   # slab 0 = the carried state of a flag=True continuation, zeros after a reset
+            t[0].copy_(state[key][idx]) if state is not None and state.get(key) is not None else t[0].zero_()
+
+        def gate_pair(a_t, blk, Co, Fo, y_ptr, ys):
+            """CRN_ELU.py:240-241: conv_trans(a) * sigmoid(conv_gated(a)) -> gLN.  Two 1x1 launches into the halves of tg."""
+            tg = _new(S, 2 * Co, T, Fo, dev=dev)
+            conv_w(3, _p(a_t), None, blk.conv_trans.weight, Co, 1, blk.conv_trans.bias, tg, S, Co, Co, T, Fo, Fo, 0, 0, 2 * Co, 0)
+            conv_w(3, _p(a_t), None, blk.conv_gated.weight, Co, 1, blk.conv_gated.bias, tg, S, Co, Co, T, Fo, Fo, 0, 0, 2 * Co, Co)
+            stt = _new(S, 2, dev=dev)
+            _run("k_tgate_fwd", 0.0, lib.se_train_gate_fwd, _p(tg), _p(blk.norm.weight), _p(blk.norm.bias), y_ptr, *ys, _p(stt), S, Co, T, Fo, 0, st())
+            return tg, stt
+
         xin = []
-        x_full = _new(N + 1, B, ch[0], T, F0, dev=dev)
-        x_full[0].copy_(state["buf"][0]) if state is not None and state["buf"] is not None else x_full[0].zero_()
-        slab = B * ch[0] * T * F0
-        _run("k_tfeat", 0.0, lib.se_train_feat, _p(spec), _p(x_full, slab), S, M, T, F0, 0, st())
+        C0 = ch[0]
+        x_full = _new(N + 1, B, C0, T, F0, dev=dev)
+        slab0 = B * C0 * T * F0
+        first_slab(x_full, "pbuf" if V else "buf", 0)
+        _run("k_tfeat", 0.0, lib.se_train_feat, _p(spec), _p(x_full, slab0), S, M, T, F0, 1 if V else 0, st())
+        pre = []
+        if V:  # x = block(x) + x, three times (CRN_ELU.py:375-376)
+            cur = x_full
+            for k, blk in enumerate(model.preconvlist):
+                a_t = _new(S, C0, T, F0, dev=dev)
+                _run("k_pre5", 2.0 * S * C0 * C0 * 25 * T * F0, lib.se_train_pre5, 0, _p(cur, slab0), _p(cur), _p(blk.conv.weight), _p(blk.conv.bias), None, _p(a_t),
+                     S, C0, T, F0, 2 ** k, 2, st())
+                out = _new(S, C0, T, F0, dev=dev)
+                tg, stt = gate_pair(a_t, blk, C0, F0, _p(out), (C0 * T * F0, T * F0, F0))
+                nxt = _new(N + 1, B, C0, T, F0, dev=dev)
+                first_slab(nxt, "pbuf", k + 1) if k < 2 else first_slab(nxt, "buf", 0)
+                _run("k_tadd", 0.0, lib.se_train_add3, _p(nxt, slab0), _p(out), _p(cur, slab0), S * C0 * T * F0, st())
+                pre.append(dict(cur=cur, a=a_t, tg=tg, st=stt))
+                cur = nxt
+            x_full = cur
         xin.append(x_full)
-        ys, stats_e = [], []
+        ys, stats_e, enc_tg = [], [], []
         seq = None
         for i, blk in enumerate(model.convlist):
             Ci, Co, Fi, Fo, d = ch[i], ch[i + 1], Fq[i], Fq[i + 1], 2 ** i
             slab = B * Ci * T * Fi
-            y = _new(S, Co, T, Fo, dev=dev)
-            conv_w(0, _p(xin[i], slab), _p(xin[i]), blk.conv.weight, Ci * 15, 15, blk.conv.bias, y, S, Ci, Co, T, Fi, Fo, d)
+            y = _new(S, Co, T, Fo, dev=dev)   # variant 0: the pre-activation; variant 1: ELU(conv), all the backward needs
+            conv_w(0, _p(xin[i], slab), _p(xin[i]), blk.conv.weight, Ci * 15, 15, blk.conv.bias, y, S, Ci, Co, T, Fi, Fo, d, 2 if V else 0)
             ys.append(y)
             if i < Lv - 1:
                 nxt = _new(N + 1, B, Co, T, Fo, dev=dev)
-                nxt[0].copy_(state["buf"][i + 1]) if state is not None and state["buf"] is not None else nxt[0].zero_()
-                stats_e.append(gln_fwd(y, (Co * T * Fo, T * Fo, Fo), _p(nxt, B * Co * T * Fo), (Co * T * Fo, T * Fo, Fo), blk.norm.weight, blk.norm.bias,
-                                       S, Co, T, Fo, Fo, 0, 1))
+                first_slab(nxt, "buf", i + 1)
+                y_ptr, ysd = _p(nxt, B * Co * T * Fo), (Co * T * Fo, T * Fo, Fo)
                 xin.append(nxt)
             else:  # the last block feeds the GRU: [S][T][D], feature index c * F + f (CRN.py:476-478)
                 D = Co * Fo
                 seq = _new(S * T, D, dev=dev)
-                stats_e.append(gln_fwd(y, (Co * T * Fo, T * Fo, Fo), _p(seq), (T * D, Fo, D), blk.norm.weight, blk.norm.bias, S, Co, T, Fo, Fo, 0, 1))
+                y_ptr, ysd = _p(seq), (T * D, Fo, D)
+            if V:
+                tg, stt = gate_pair(y, blk, Co, Fo, y_ptr, ysd)
+                enc_tg.append(tg)
+                stats_e.append(stt)
+            else:
+                stats_e.append(gln_fwd(y, (Co * T * Fo, T * Fo, Fo), y_ptr, ysd, blk.norm.weight, blk.norm.bias, S, Co, T, Fo, Fo, 0, 1))
         CL, FL = ch[Lv], Fq[Lv]
         D = CL * FL
         g = model.gru.sequence_model
@@ -210,7 +249,7 @@ class CRNFunction(torch.autograd.Function):
         fc = model.gru.fc_output_layer
         o_fc = K._gemm(layer_in, fc.weight, fc.bias)  # [R, D] pre-activation
         xd = _new(S, CL, T, FL, dev=dev)
-        st_fc = gln_fwd(o_fc, (T * D, FL, D), _p(xd), (CL * T * FL, T * FL, FL), model.gru.norm.weight, model.gru.norm.bias, S, CL, T, FL, FL, 1, 1)
+        st_fc = gln_fwd(o_fc, (T * D, FL, D), _p(xd), (CL * T * FL, T * FL, FL), model.gru.norm.weight, model.gru.norm.bias, S, CL, T, FL, FL, 1, act)
         dec = []
         x_in = xd
         Ci, Fi = CL, FL
@@ -226,7 +265,7 @@ class CRNFunction(torch.autograd.Function):
                 if Fr < Fy or Cr != Co:
                     raise RuntimeError("decoder / skip geometry outside the reference's (CRN.py:389-392 crop branch is never taken)")
                 z = _new(S, Co, T, Fr, dev=dev)
-                rec["st"] = gln_fwd(yd, (Co * T * Fy, T * Fy, Fy), _p(z), (Co * T * Fr, T * Fr, Fr), blk.norm.weight, blk.norm.bias, S, Co, T, Fy, Fr, 0, 1)
+                rec["st"] = gln_fwd(yd, (Co * T * Fy, T * Fy, Fy), _p(z), (Co * T * Fr, T * Fr, Fr), blk.norm.weight, blk.norm.bias, S, Co, T, Fy, Fr, 0, act)
                 wuv = _new(2 * Co, Cr, dev=dev)
                 buv = _new(2 * Co, dev=dev)
                 wuv[:Co].copy_(blk.residual.weight.view(Co, Cr)); wuv[Co:].copy_(blk.residualmask.weight.view(Co, Cr))
@@ -237,12 +276,12 @@ class CRNFunction(torch.autograd.Function):
                 out = _new(S, Co, T, Fr, dev=dev)
                 st_uv = _new(S, 2, dev=dev)
                 _run("k_tskip_fwd", 0.0, lib.se_train_skip_fwd, _p(uv), _p(z), _p(blk.residualnorm.weight), _p(blk.residualnorm.bias), _p(out), _p(st_uv),
-                     S, Co, T, Fr, 1, 0, st())
+                     S, Co, T, Fr, act, 0, st())
                 rec.update(z=z, uv=uv, wuv=wuv, st_uv=st_uv, k=k, Cr=Cr, Fr=Fr)
                 x_in, Ci, Fi = out, Co, Fr
             else:
                 xl = _new(S, Co, T, Fy, dev=dev)
-                rec["st"] = gln_fwd(yd, (Co * T * Fy, T * Fy, Fy), _p(xl), (Co * T * Fy, T * Fy, Fy), blk.norm.weight, blk.norm.bias, S, Co, T, Fy, Fy, 0, 1)
+                rec["st"] = gln_fwd(yd, (Co * T * Fy, T * Fy, Fy), _p(xl), (Co * T * Fy, T * Fy, Fy), blk.norm.weight, blk.norm.bias, S, Co, T, Fy, Fy, 0, act)
                 rec["xl"] = xl
                 if Co != 2 or Fy != F0:
                     raise RuntimeError("last decoder block must produce the 2-channel mask at full resolution")
@@ -256,12 +295,10 @@ class CRNFunction(torch.autograd.Function):
         pred = _new(B, Lout, dev=dev)
         _run("k_tola", 0.0, lib.se_train_ola_fwd, sig, _p(yseg), _p(pred), B, Lout, skip, st())
         # carried state for a flag=True continuation: the last segment's block inputs and the GRU state (detached by construction)
-        model._state = dict(buf=[xin[i][N] for i in range(Lv)], h=hTs)
+        model._state = dict(buf=[xin[i][N] for i in range(Lv)], h=hTs, pbuf=[r["cur"][N] for r in pre] if V else None)
         ctx.model = model
         ctx.dims = dict(B=B, M=M, L=Lout, N=N, S=S, T=T, F0=F0, Ks=Ks, skip=skip, ch=ch, Fq=Fq, Lv=Lv, H=H, NL=NL, D=D, CL=CL, FL=FL, n_fft=n_fft, sig=sig)
-        ctx.sv = dict(spec=spec, xin=xin, ys=ys, stats_e=stats_e, seq=seq, outs=outs, gates=gates, h0s=h0s, o_fc=o_fc, st_fc=st_fc, dec=dec, xl=xl)
-        ctx.params = params
-        ctx.mark_non_differentiable()
+        ctx.sv = dict(V=V, act=act, pre=pre, enc_tg=enc_tg, spec=spec, xin=xin, ys=ys, stats_e=stats_e, seq=seq, outs=outs, gates=gates, h0s=h0s, o_fc=o_fc, st_fc=st_fc, dec=dec, xl=xl)
         return pred
 
     @staticmethod
@@ -274,6 +311,7 @@ class CRNFunction(torch.autograd.Function):
         st = K._st
         dpred = dpred.contiguous()
         grads = {}
+        V, act = sv["V"], sv["act"]
         zero_bias = torch.zeros(256, device=dev)
 
         gseg = _new(S, Ks, dev=dev)
@@ -294,7 +332,7 @@ class CRNFunction(torch.autograd.Function):
                 dz = _new(S, Co, T, Fr, dev=dev)
                 pw, pb, pbias = _new(S, Co, dev=dev), _new(S, Co, dev=dev), _new(S, 2 * Co, dev=dev)
                 _run("k_tskip_bwd", 0.0, lib.se_train_skip_bwd, _p(dout), _p(rec["uv"]), _p(rec["z"]), _p(blk.residualnorm.weight), _p(blk.residualnorm.bias),
-                     _p(rec["st_uv"]), _p(duv), _p(dz), _p(pw), _p(pb), _p(pbias), S, Co, T, Fr, 1, 0, st())
+                     _p(rec["st_uv"]), _p(duv), _p(dz), _p(pw), _p(pb), _p(pbias), S, Co, T, Fr, act, 0, st())
                 dnw, dnb, dbuv = colsum3(S, (pw, Co), (pb, Co), (pbias, 2 * Co))
                 grads[pre + "residualnorm.weight"], grads[pre + "residualnorm.bias"] = dnw, dnb
                 grads[pre + "residual.bias"], grads[pre + "residualmask.bias"] = dbuv[:Co], dbuv[Co:]
@@ -307,7 +345,7 @@ class CRNFunction(torch.autograd.Function):
                 dy_ptr, ds = _p(dz), (Co * T * Fr, T * Fr, Fr)
             else:
                 dy_ptr, ds = _p(dout), (Co * T * Fy, T * Fy, Fy)
-            dyd, dw, db, dpre = gln_bwd(dy_ptr, ds, rec["yd"], (Co * T * Fy, T * Fy, Fy), blk.norm.weight, rec["st"], S, Co, T, Fy, 0, 1)
+            dyd, dw, db, dpre = gln_bwd(dy_ptr, ds, rec["yd"], (Co * T * Fy, T * Fy, Fy), blk.norm.weight, rec["st"], S, Co, T, Fy, 0, act)
             grads[pre + "norm.weight"], grads[pre + "norm.bias"], grads[pre + "conv.bias"] = dw, db, dpre
             grads[pre + "conv.weight"] = wgrad(rec["x_in"], dyd, None, S, Ci, Co, T, Fi, Fy, d, 15)
             din = _new(S, Ci, T, Fi, dev=dev)
@@ -316,7 +354,7 @@ class CRNFunction(torch.autograd.Function):
         # bottleneck: gLN(last) + ReLU + fc, then the GRU layers in reverse
         R = S * T
         fc = model.gru.fc_output_layer
-        do_fc, dw, db, dpre = gln_bwd(_p(dout), (CL * T * FL, T * FL, FL), sv["o_fc"], (T * D, FL, D), model.gru.norm.weight, sv["st_fc"], S, CL, T, FL, 1, 1)
+        do_fc, dw, db, dpre = gln_bwd(_p(dout), (CL * T * FL, T * FL, FL), sv["o_fc"], (T * D, FL, D), model.gru.norm.weight, sv["st_fc"], S, CL, T, FL, 1, act)
         grads["gru.norm.weight"], grads["gru.norm.bias"], grads["gru.fc_output_layer.bias"] = dw, db, dpre
         top = sv["outs"][NL - 1]
         grads["gru.fc_output_layer.weight"] = gemm_tn(do_fc, top)
@@ -335,17 +373,40 @@ class CRNFunction(torch.autograd.Function):
             grads[f"gru.sequence_model.bias_ih_l{l}"] = colsum_tall(dgi)
             grads[f"gru.sequence_model.bias_hh_l{l}"] = colsum_tall(dgh)
             dlayer = K._gemm(dgi, transpose(w_ih))  # [R, In]
+        def gate_pair_bwd(dy_ptr, ds, a_t, tg, stt, blk, Co, Fo, pre):
+            """through gLN + gated pair + ELU: returns dy of the convolution that produced a_t (in place in a fresh tensor)."""
+            dtg = _new(S, 2 * Co, T, Fo, dev=dev)
+            pw, pb, pbias = _new(S, Co, dev=dev), _new(S, Co, dev=dev), _new(S, 2 * Co, dev=dev)
+            _run("k_tgate_bwd", 0.0, lib.se_train_gate_bwd, dy_ptr, *ds, _p(tg), _p(blk.norm.weight), _p(stt), _p(dtg), _p(pw), _p(pb), _p(pbias), S, Co, T, Fo, 0, st())
+            dnw, dnb, dbtg = colsum3(S, (pw, Co), (pb, Co), (pbias, 2 * Co))
+            grads[pre + "norm.weight"], grads[pre + "norm.bias"] = dnw, dnb
+            grads[pre + "conv_trans.bias"], grads[pre + "conv_gated.bias"] = dbtg[:Co], dbtg[Co:]
+            dwtg = wgrad(dtg, a_t, None, S, 2 * Co, Co, T, Fo, Fo, 0, 1).view(2 * Co, Co)
+            grads[pre + "conv_trans.weight"], grads[pre + "conv_gated.weight"] = dwtg[:Co], dwtg[Co:]
+            wst = _new(2 * Co, Co, dev=dev)   # [conv_trans; conv_gated] stacked: d a = W^T dtg in one 2Co-deep contraction
+            wst[:Co].copy_(blk.conv_trans.weight.view(Co, Co)); wst[Co:].copy_(blk.conv_gated.weight.view(Co, Co))
+            da = _new(S, Co, T, Fo, dev=dev)
+            conv_w(3, _p(dtg), None, wst, 1, Co, zero_bias, da, S, 2 * Co, Co, T, Fo, Fo, 0)
+            pp = _new(S, Co, dev=dev)
+            _run("k_telu_bwd", 0.0, lib.se_train_elu_bwd, _p(da), _p(a_t), _p(pp), S, Co, T, Fo, st())
+            grads[pre + "conv.bias"] = colsum3(S, (pp, Co))[0]
+            return da
+
         # encoder, last block first; dlayer = d seq [S][T][D]
         dy_ptr, ds = _p(dlayer), (T * D, FL, D)
+        dx0 = None
         for i in range(Lv - 1, -1, -1):
             blk = model.convlist[i]
             Ci, Co, Fi, Fo, d = ch[i], ch[i + 1], Fq[i], Fq[i + 1], 2 ** i
             pre = f"convlist.{i}."
-            dy, dw, db, dpre = gln_bwd(dy_ptr, ds, sv["ys"][i], (Co * T * Fo, T * Fo, Fo), blk.norm.weight, sv["stats_e"][i], S, Co, T, Fo, 0, 1)
-            grads[pre + "norm.weight"], grads[pre + "norm.bias"], grads[pre + "conv.bias"] = dw, db, dpre
+            if V:
+                dy = gate_pair_bwd(dy_ptr, ds, sv["ys"][i], sv["enc_tg"][i], sv["stats_e"][i], blk, Co, Fo, pre)
+            else:
+                dy, dw, db, dpre = gln_bwd(dy_ptr, ds, sv["ys"][i], (Co * T * Fo, T * Fo, Fo), blk.norm.weight, sv["stats_e"][i], S, Co, T, Fo, 0, 1)
+                grads[pre + "norm.weight"], grads[pre + "norm.bias"], grads[pre + "conv.bias"] = dw, db, dpre
             slab = B * Ci * T * Fi
             grads[pre + "conv.weight"] = wgrad(dy, _p(sv["xin"][i], slab), _p(sv["xin"][i]), S, Co, Ci, T, Fo, Fi, d, 15)
-            if i == 0:
+            if i == 0 and not V:
                 break  # the features carry no gradient
             dxi = _new(S, Ci, T, Fi, dev=dev)
             for kind in (1, 2):
@@ -353,6 +414,24 @@ class CRNFunction(torch.autograd.Function):
             if i in dres:
                 _run("k_tadd", 0.0, lib.se_train_add, _p(dxi), _p(dres[i]), dxi.numel(), st())
             dy_ptr, ds = _p(dxi), (Ci * T * Fi, T * Fi, Fi)
+            dx0 = dxi
+        if V:  # the pre-conv chain, last block first: x_{k+1} = block_k(x_k) + x_k
+            C0, slab0 = ch[0], B * ch[0] * T * F0
+            dnxt = dx0
+            for k in range(2, -1, -1):
+                blk, r = model.preconvlist[k], sv["pre"][k]
+                pre = f"preconvlist.{k}."
+                dyk = gate_pair_bwd(_p(dnxt), (C0 * T * F0, T * F0, F0), r["a"], r["tg"], r["st"], blk, C0, F0, pre)
+                part = _new(S, C0 * C0 * 25, dev=dev)
+                _run("k_pre5", 2.0 * S * C0 * C0 * 25 * T * F0, lib.se_train_pre5, 2, _p(r["cur"], slab0), _p(r["cur"]), _p(blk.conv.weight), None, _p(dyk), _p(part),
+                     S, C0, T, F0, 2 ** k, 0, st())
+                grads[pre + "conv.weight"] = colsum3(S, (part, C0 * C0 * 25))[0]
+                if k == 0:
+                    break  # block 0 reads the features
+                dcur = _new(S, C0, T, F0, dev=dev)
+                _run("k_pre5", 2.0 * S * C0 * C0 * 25 * T * F0, lib.se_train_pre5, 1, None, None, _p(blk.conv.weight), None, _p(dyk), _p(dcur), S, C0, T, F0, 2 ** k, 0, st())
+                _run("k_tadd", 0.0, lib.se_train_add, _p(dcur), _p(dnxt), dcur.numel(), st())
+                dnxt = dcur
         out = []
         for (name, p) in model.named_parameters():
             gname = name.replace(".net.0.", ".conv.")

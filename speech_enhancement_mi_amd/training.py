@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as Fn
 
 from .crn import TemporalCRN
+from .crn_elu import TemporalCRN as TemporalCRNELU
 from .losses import cal_si_snr
 
 EPS = 1e-8
@@ -32,9 +33,9 @@ def _gln(x, w, b):
     return (x - mean) / (torch.sqrt(var + EPS) + EPS) * w + b
 
 
-class TrainableCRN(TemporalCRN):
-    """CRN.py TemporalCRN (variant 0) with a differentiable torch forward.  Same parameters / state_dict as the inference
-    shim, so a checkpoint trained here loads into the HIP engine unchanged."""
+class _TrainableMixin:
+    """Differentiable `realtime_process` on top of the drop-in parameter holders (crn.TemporalCRN / crn_elu.TemporalCRN).  Same
+    parameters / state_dict as the inference shim, so a checkpoint trained here loads into the HIP engine unchanged."""
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -80,13 +81,27 @@ class TrainableCRN(TemporalCRN):
         y = torch.istft(spec.reshape(-1, *spec.shape[-2:]), self._nfft, self._hop, self._win, w, center=True, normalized=False, onesided=True)
         return y.reshape(*shp, y.shape[-1])
 
-    # ---- one segment, CRN.py:454-496 ----
+    # ---- one segment, CRN.py:454-496 (variant 0) / CRN_ELU.py:367-407 (variant 1) ----
     def _forward_segment(self, X, state):
-        """X [B, M, F, T] complex; state = dict(buf=[...], h=tensor|None) (detached, like CRN.py:281,334)."""
+        """X [B, M, F, T] complex; state = dict(buf=[...], h=tensor|None, pbuf=[...]) (detached, like CRN.py:281,334)."""
+        V = self._VARIANT
+        actf = Fn.elu if V else torch.relu
         re, im = X.real, X.imag
-        ang = torch.atan(im / (re + EPS) + EPS)
+        ang = torch.atan2(im, re) if V else torch.atan(im / (re + EPS) + EPS)
         mag = torch.sqrt(re ** 2 + im ** 2 + 1e-10)
         x = torch.cat([mag, ang[:, :1] - ang[:, 1:]], dim=1)
+
+        def gated(blk, a):  # CRN_ELU.py:240
+            return Fn.conv2d(a, blk.conv_trans.weight, blk.conv_trans.bias) * torch.sigmoid(Fn.conv2d(a, blk.conv_gated.weight, blk.conv_gated.bias))
+
+        new_pbuf = []
+        if V:
+            for k, blk in enumerate(self.preconvlist):  # x = block(x) + x, CRN_ELU.py:375-376
+                fd = 2 ** k
+                buf = state["pbuf"][k] if state.get("pbuf") is not None else x.new_zeros(x.shape[0], x.shape[1], x.shape[2], 4)
+                y = Fn.conv2d(torch.cat([buf, x], dim=-1), blk.conv.weight, blk.conv.bias, stride=(1, 1), padding=(2 * fd, 0), dilation=(fd, 1))
+                new_pbuf.append(x[..., -4:].detach())
+                x = _gln(gated(blk, actf(y)), blk.norm.weight, blk.norm.bias) + x
         residuals = [x]
         new_buf = []
         for i, blk in enumerate(self.convlist):
@@ -96,19 +111,19 @@ class TrainableCRN(TemporalCRN):
             inp = torch.cat([buf, x], dim=-1)
             y = Fn.conv2d(inp, blk.conv.weight, blk.conv.bias, stride=(2, 1), padding=(2, 0), dilation=(1, d))
             new_buf.append(x[..., -P:].detach())
-            x = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            x = _gln(gated(blk, actf(y)) if V else actf(y), blk.norm.weight, blk.norm.bias)
             residuals.append(x)
         B, C, Fq, T = x.shape
         seq = x.reshape(B, C * Fq, T).permute(0, 2, 1)
         o, h = self.gru.sequence_model(seq, state["h"])
-        o = torch.relu(self.gru.fc_output_layer(o))
+        o = actf(self.gru.fc_output_layer(o))
         o = _gln(o.unsqueeze(1), self.gru.norm.weight, self.gru.norm.bias).squeeze(1)
         x = o.permute(0, 2, 1).reshape(B, C, Fq, T)
         L = len(self.deconvlist)
         for j, blk in enumerate(self.deconvlist):
             d = 2 ** j
             y = Fn.conv_transpose2d(x, blk.conv.weight, blk.conv.bias, stride=(2, 1), padding=(2, 0), dilation=(1, d))[..., -T:]
-            y = _gln(torch.relu(y), blk.norm.weight, blk.norm.bias)
+            y = _gln(actf(y), blk.norm.weight, blk.norm.bias)
             if j < L - 1:
                 res = residuals[-2 - j]
                 if res.shape[2] > y.shape[2]:
@@ -116,12 +131,12 @@ class TrainableCRN(TemporalCRN):
                 elif res.shape[2] < y.shape[2]:
                     y = y[:, :, :res.shape[2]]
                 m = torch.sigmoid(_gln(Fn.conv2d(res, blk.residualmask.weight, blk.residualmask.bias), blk.residualnorm.weight, blk.residualnorm.bias))
-                y = m * torch.relu(Fn.conv2d(res, blk.residual.weight, blk.residual.bias)) + (1.0 - m) * y
+                y = m * actf(Fn.conv2d(res, blk.residual.weight, blk.residual.bias)) + (1.0 - m) * y
             x = y
         m = x.clamp(-9.9, 9.9)  # decompress_cIRM, utility.py:439-442 (the clamp has zero gradient outside, like the reference's masks)
         m = -10.0 * torch.log((10.0 - m) / (10.0 + m))
         Y = torch.complex(m[:, 0] * re[:, 0] - m[:, 1] * im[:, 0], m[:, 1] * re[:, 0] + m[:, 0] * im[:, 0])
-        return Y, dict(buf=new_buf, h=h.detach())
+        return Y, dict(buf=new_buf, h=h.detach(), pbuf=new_pbuf if V else None)
 
     def realtime_process_train(self, mixture, flag=False):
         """Differentiable realtime_process (CRN.py:560-589): [B, M, L] -> [B, L]."""
@@ -134,7 +149,7 @@ class TrainableCRN(TemporalCRN):
         P = K // 2
         if not flag:
             mixture = Fn.pad(mixture, (P, 0))
-            self._state = dict(buf=None, h=None)
+            self._state = dict(buf=None, h=None, pbuf=None)
         seg, gap = self._segment(mixture)  # [B, M, N, K]
         X = self._stft(seg)  # [B, M, N, F, T]
         state = self._state
@@ -151,6 +166,14 @@ class TrainableCRN(TemporalCRN):
         if gap > 0:
             out = out[:, :-gap]
         return out if flag else out[:, P:]
+
+
+class TrainableCRN(_TrainableMixin, TemporalCRN):
+    """CRN.py TemporalCRN (variant 0), trainable."""
+
+
+class TrainableCRNELU(_TrainableMixin, TemporalCRNELU):
+    """CRN_ELU.py TemporalCRN (variant 1) - the model the reference's train.py imports and trains (train.py:16)."""
 
 
 def si_snr_loss(pred, source, length=None):

@@ -469,3 +469,94 @@ def test_stoi_resampler_at_the_shape_of_the_round2_fault():
     loss = losses.compute_loss(src, pred, lens)[0]
     loss.backward()
     assert bool(torch.isfinite(big.grad).all()) and float(big.grad[:, :1600].abs().max()) == 0.0
+
+
+# ---- CRN_ELU (the model train.py:16 trains) on the training kernels ---------------------------------------------------------------
+def test_fused_pre5_and_gate_ops_vs_autograd():
+    """The CRN_ELU deltas as kernels: the 5-channel 5x5 frequency-dilated pre-conv (forward with ELU, input gradient, weight-gradient
+    slab; CRN_ELU.py:335-340 with history rows) and the gated 1x1 pair + norm (k_tgate_fwd / _bwd; CRN_ELU.py:240-241)."""
+    import torch.nn.functional as Fn
+    from speech_enhancement_mi_amd import train_ops as K
+    lib = K._lib()
+    torch.manual_seed(11)
+    S, C, T, F, fd = 4, 5, 21, 201, 2
+    x = torch.randn(S, C, T, F, device="cuda", requires_grad=True)
+    xp = torch.randn(S, C, T, F, device="cuda")
+    w = (torch.randn(C, C, 5, 5, device="cuda") * 0.2).requires_grad_(True)
+    b = torch.randn(C, device="cuda", requires_grad=True)
+    a = torch.empty(S, C, T, F, device="cuda")
+    K._chk(lib.se_train_pre5(0, x.data_ptr(), xp.data_ptr(), w.data_ptr(), b.data_ptr(), None, a.data_ptr(), S, C, T, F, fd, 2, K._st()))
+    # reference layout [B, C, F, T]: cat(buffer = last 4 frames of xp, x) -> Conv2d((5,5), dilation (fd,1), padding (2fd,0)) -> ELU
+    inp = torch.cat([xp[:, :, -4:].permute(0, 1, 3, 2), x.permute(0, 1, 3, 2)], dim=-1)
+    ar = Fn.elu(Fn.conv2d(inp, w, b, padding=(2 * fd, 0), dilation=(fd, 1))).permute(0, 1, 3, 2)
+    assert a.shape == ar.shape and _rel(a, ar) < 1e-5
+    g = torch.randn(*ar.shape, device="cuda")   # (randn_like would inherit the permuted strides of the reference-layout tensor)
+    ar.backward(g)
+    dy = g * torch.where(a > 0, torch.ones_like(a), a + 1)          # ELU' from the saved activation
+    dx = torch.empty_like(a)
+    K._chk(lib.se_train_pre5(1, None, None, w.data_ptr(), None, dy.data_ptr(), dx.data_ptr(), S, C, T, F, fd, 0, K._st()))
+    part = torch.empty(S, C * C * 25, device="cuda")
+    K._chk(lib.se_train_pre5(2, x.data_ptr(), xp.data_ptr(), w.data_ptr(), None, dy.data_ptr(), part.data_ptr(), S, C, T, F, fd, 0, K._st()))
+    assert _rel(dx, x.grad) < 2e-5 and _rel(part.sum(0).view(C, C, 5, 5), w.grad) < 2e-5
+    pp = torch.empty(S, C, device="cuda")
+    da = g.clone()
+    K._chk(lib.se_train_elu_bwd(da.data_ptr(), a.data_ptr(), pp.data_ptr(), S, C, T, F, K._st()))
+    assert _rel(da, dy) < 1e-6 and _rel(pp.sum(0), b.grad) < 2e-5
+    # gated pair + norm, output written in the GRU layout [S][T][C*F]
+    Cg, Fg = 32, 13
+    tg = torch.randn(S, 2 * Cg, T, Fg, device="cuda", requires_grad=True)
+    nw, nb = torch.randn(Cg, device="cuda", requires_grad=True), torch.randn(Cg, device="cuda", requires_grad=True)
+    D = Cg * Fg
+    y = torch.empty(S * T, D, device="cuda")
+    stt = torch.empty(S, 2, device="cuda")
+    K._chk(lib.se_train_gate_fwd(tg.data_ptr(), nw.data_ptr(), nb.data_ptr(), y.data_ptr(), T * D, Fg, D, stt.data_ptr(), S, Cg, T, Fg, 0, K._st()))
+    p = tg[:, :Cg] * torch.sigmoid(tg[:, Cg:])
+    yr = _gln_ref(p, nw.view(1, Cg, 1, 1), nb.view(1, Cg, 1, 1)).permute(0, 2, 1, 3).reshape(S * T, D)
+    assert _rel(y, yr) < 1e-5
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    dtg = torch.empty(S, 2 * Cg, T, Fg, device="cuda")
+    pw, pb, pbias = torch.empty(S, Cg, device="cuda"), torch.empty(S, Cg, device="cuda"), torch.empty(S, 2 * Cg, device="cuda")
+    K._chk(lib.se_train_gate_bwd(gy.data_ptr(), T * D, Fg, D, tg.data_ptr(), nw.data_ptr(), stt.data_ptr(), dtg.data_ptr(), pw.data_ptr(), pb.data_ptr(),
+                                 pbias.data_ptr(), S, Cg, T, Fg, 0, K._st()))
+    assert _rel(dtg, tg.grad) < 2e-5 and _rel(pw.sum(0), nw.grad) < 2e-5 and _rel(pb.sum(0), nb.grad) < 2e-5
+    assert _rel(pbias.sum(0), tg.grad.sum((0, 2, 3))) < 2e-4
+
+
+@pytest.mark.parametrize("cfgname,utts,seconds", [("tiny", 2, 0.5), ("full400", 4, 1.0)])
+def test_fused_crn_elu_train_step_vs_float64_autograd(cfgname, utts, seconds):
+    """CRN_ELU (variant 1) on the training kernels: prediction, continuation and the whole flat gradient against torch autograd in
+    float64 (fed the same fp32 spectrum: atan2 phase jumps at re = -0), next to torch's own fp32 kernels."""
+    from speech_enhancement_mi_amd import train_net as N, train_ops as K
+    from speech_enhancement_mi_amd.training import TrainableCRNELU
+    cfg = TINY if cfgname == "tiny" else FULL400
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec_of_variant(cfg, 1), seed=3).items()}
+    L = int(seconds * 16000)
+    mix, clean = synth.synth_utterances(utts, L + 4800, 3, seed=91)
+    x, c = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
+
+    def hip_stft(seg):
+        rows = seg.reshape(-1, seg.shape[-1]).float().contiguous()
+        spec = torch.empty(rows.shape[0], 21, 201, 2, device="cuda")
+        K._chk(K._lib().se_sig_stft(N._sig(rows.device, 400, 400, 160, 3200), rows.data_ptr(), rows.shape[0], 1, 3200, 0, 0, 1, spec.data_ptr(), K._st()))
+        X = torch.view_as_complex(spec).permute(0, 2, 1).reshape(*seg.shape[:-1], 201, 21)
+        return X.to(torch.complex128 if seg.dtype == torch.float64 else torch.complex64)
+
+    def run(hip, dtype):
+        m = TrainableCRNELU(**cfg)
+        m.load_state_dict(sd)
+        m = m.cuda().to(dtype).use_hip_kernels(hip)
+        if not hip:
+            m._stft = hip_stft
+        y1 = m.realtime_process_train(x[..., :L].contiguous().to(dtype))
+        y2 = m.realtime_process_train(x[..., L:].contiguous().to(dtype), flag=True)
+        loss = ((y1 - c[:, :L].to(dtype)) ** 2).mean() * 100 + ((y2 - c[:, L:].to(dtype)) ** 2).mean() * 100
+        loss.backward()
+        g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
+        return y1.detach().double(), y2.detach().double(), g.double()
+
+    r64, r32, rh = run(False, torch.float64), run(False, torch.float32), run(True, torch.float32)
+    assert _rel(rh[0], r64[0]) < 2e-5 and _rel(rh[1], r64[1]) < 2e-5
+    e_t, e_h = _rel(r32[2], r64[2]), _rel(rh[2], r64[2])
+    print(f"CRN_ELU flat-gradient error vs float64 autograd: torch fp32 {e_t:.2e}, training kernels {e_h:.2e}")
+    assert e_h < max(3.0 * e_t, 1e-4), (e_h, e_t)

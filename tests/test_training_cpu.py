@@ -33,6 +33,25 @@ def test_trainable_forward_matches_oracle():
     assert rel_rms(y2, o.realtime_process(mix[..., 6400:], flag=True)) < 1e-5
 
 
+def test_trainable_crn_elu_forward_matches_oracle():
+    """The CRN_ELU restatement (variant 1: atan2 phase, three 5x5 pre-conv blocks with residual, ELU, gated 1x1 pair per block;
+    CRN_ELU.py:194-252, 335-407) - the comparator of the variant-1 training kernels - against the C oracle, incl. a continuation."""
+    from conftest import spec_of_variant
+    from oracle import crn_oracle as orc
+    from speech_enhancement_mi_amd.training import TrainableCRNELU
+    m = TrainableCRNELU(**TINY)
+    sd = synth.make_state_dict(spec_of_variant(TINY, 1), seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    o = orc.CrnOracle(**TINY, variant=1)
+    o.load_state_dict(sd)
+    mix, _ = synth.synth_utterances(2, 6400 + 3200, 3, seed=9)
+    with torch.no_grad():
+        y = m.realtime_process_train(torch.from_numpy(mix[..., :6400])).numpy()
+        y2 = m.realtime_process_train(torch.from_numpy(mix[..., 6400:]), flag=True).numpy()
+    assert rel_rms(y, o.realtime_process(mix[..., :6400])) < 1e-5
+    assert rel_rms(y2, o.realtime_process(mix[..., 6400:], flag=True)) < 1e-5
+
+
 def test_loss_backward_and_flat_bucket():
     from speech_enhancement_mi_amd.training import FlatBucket, si_snr_loss, train_step
     m = _model()
