@@ -330,9 +330,49 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
     mix, clean = synth.synth_utterances(U, L, 3, seed=2000 + rank)
     mix, clean = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
     last = {}
+    gen_ms = []
+    if args.data == "gen":
+        # SURVEY 8f-4 wired into the step: every step draws U fresh rooms (config.yaml:77-88 ranges) and simulates its own batch ON THE GPU
+        # (image-source RIRs + diffuse tail, dry speech * RIR, SNR mix ~ U[-5, 25] dB, MAX_AMP guard) from a device-resident pool of dry
+        # signals - the stand-in for data_c.LibriPartyDataset + multichannel.Single2Multi, which kept the reference single-GPU (README.md:24)
+        from speech_enhancement_mi_amd.datagen import Single2Multi
+        sim = Single2Multi(((3, 3, 2.5), (4, 5, 3)), (0.2, 1.0), ((0.5,) * 6, (1.0,) * 6), ((0.1, 0.1, 0.2), (0.9, 0.9, 0.7)),
+                           ((0.06, 0.06, 0.06), (0.15, 0.15, 0.15)), ((0.0, 0.0, 0.3), (1.0, 1.0, 0.7)), num_src=1, num_mic=3)
+        _, dry = synth.synth_utterances(64, L, 1, seed=3000 + rank)
+        dry_pool = torch.from_numpy(dry).cuda()
+        noise_pool = torch.randn(64, L, device="cuda") * 0.1
+        rng = np.random.default_rng(17 + rank)
+
+        def make_batch():
+            rb = sim.sample(U, rng, snr_low=-5.0, snr_high=25.0)
+            i1 = torch.from_numpy(rng.integers(0, 64, U)).cuda()
+            i2 = torch.from_numpy(rng.integers(0, 64, U)).cuda()
+            srcs = torch.stack([dry_pool[i1], noise_pool[i2]], dim=1).contiguous()
+            mx, y, _ = sim.simulate(srcs, rb, rir=sim.rir(rb, "cuda", diffuse=True, seed=int(rng.integers(0, 2 ** 31))))
+            return mx, y[:, 0, 0].contiguous()
+
+        gen_stream = torch.cuda.Stream()
+        pending = {}
+
+        def prefetch():  # the NEXT step's batch is generated on a side stream while this step trains
+            with torch.cuda.stream(gen_stream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                pending["batch"] = make_batch()
+                e1.record()
+                pending["ready"] = e1
+                gen_ms.append((e0, e1))
+
+        prefetch()
 
     def step():
-        last["loss"] = train_step(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss, merge=not args.no_merge)
+        if args.data == "gen":
+            torch.cuda.current_stream().wait_event(pending["ready"])
+            mx, tgt = pending["batch"]
+            prefetch()
+        else:
+            mx, tgt = mix, clean
+        last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge)
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
@@ -358,13 +398,16 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
                         step_ms_profiled=sum(v["ms"] for v in prof.values()))
     result = dict(metric=f"DP training utterances/sec ({'CRN_ELU' if variant else 'TemporalCRN'}, 3 s utterances)", value=value, unit="utterances/s", n_gpus=world,
                   steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, higher_is_better=True, scaling="weak",
-                  vs_baseline=None, dtype="f32", data="synthetic",
+                  vs_baseline=None, dtype="f32", data="synthetic" if args.data != "gen" else "synthetic, generated on the GPU inside every step (rooms, RIRs, mix)",
                   config=dict(workload=f"{'CRN_ELU (CRN_ELU.py, the model train.py:16 trains)' if variant else 'TemporalCRN (CRN.py)'} 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
                                        f"loss = {args.train_loss}, accum {args.accum} ({'micro-batches share one forward/backward sweep, loss formed per micro-batch: same gradient' if not args.no_merge else 'micro-batches run one after the other'}), "
                                        f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
                               reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
                   roofline=roofline, cpu_baseline=None)
+    if gen_ms:
+        torch.cuda.synchronize()
+        result["config"]["generator_ms_per_step"] = float(np.mean([a.elapsed_time(b) for a, b in gen_ms[warmup:]]))
     del model, bucket, opt, mix, clean
     torch.cuda.empty_cache()
     return result
@@ -599,6 +642,8 @@ def parse_args(argv=None):
                     help="--mode train: full = 0.7 * stoi_loss + 0.3 * (-SI-SNR) (CRN.py:609-611); sisnr = the SI-SNR term alone")
     ap.add_argument("--train-model", choices=["crn", "crn_elu"], default="crn", help="--mode train: CRN.py (BASELINE configs[3]) or CRN_ELU.py (what train.py imports)")
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
+    ap.add_argument("--data", choices=["fixed", "gen"], default="fixed",
+                    help="--mode train: fixed = one resident synthetic batch; gen = a fresh batch of simulated rooms per step from the GPU generator")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")

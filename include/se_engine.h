@@ -304,6 +304,10 @@ int se_train_gemm_tn_det(const float *A, const float *B, float *ws, int *nsplit_
 const char *se_synth_last_error(void);
 int se_synth_rir(const float *room, const float *beta, const float *src, const float *mic, int R, int S, int M, int nx, int ny, int nz,
                  float fs, float c, int Lr, float *rir, void *stream);
+/* optional second stage of gpuRIR (PARITY UNPINNED): for samples n >= tdiff[r] * fs the image-source response is replaced by a
+ * stochastic tail, rms(last 10 ms before Tdiff) * exp(-6.9078 (n - Td) / (T60 fs)) * unit-variance logistic noise from a
+ * counter-based hash of (seed, RIR index, n); tdiff / t60 [R] device arrays in seconds */
+int se_synth_rir_tail(float *rir, const float *tdiff, const float *t60, int R, int S, int M, int Lr, float fs, uint32_t seed, void *stream);
 int se_synth_fir(const float *x, const float *rir, int R, int S, int M, int64_t L, int Lr, float *y, void *stream);
 int se_synth_mix(const float *y, const float *snr_db, int R, int S, int M, int64_t L, float max_amp, float *mix, float *noise, float *absmax,
                  void *stream);

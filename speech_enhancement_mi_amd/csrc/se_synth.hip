@@ -49,6 +49,37 @@ __device__ __forceinline__ void image_axis(int n, float L, float xs, float b0, f
     amp = powf(b0, (float)r0) * powf(b1, (float)r1);
 }
 
+// Diffuse reverberation tail (gpuRIR's second stage: the image-source model up to Tdiff, a stochastic exponential decay from Tdiff to
+// Tmax; multichannel.py:46-52 passes both times).  PARITY UNPINNED: gpuRIR is absent and the reference holds no RIR fixture; what is
+// restated is the published idea - for n >= Td the response is zero-mean noise whose power envelope continues the image-source part
+// with the Sabine decay exp(-13.8155 t / T60): tail[n] = rms(h[Td - W, Td)) * exp(-6.9078 (n - Td) / (T60 fs)) * xi[n], xi = a
+// unit-variance logistic variate (gpuRIR's choice) from a counter-based hash (reproducible, no state).  One workgroup per RIR.
+__device__ __forceinline__ uint32_t synth_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_rir_tail(float *rir, const float *tdiff, const float *t60, int S, int M, int Lr, float fs, uint32_t seed) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, s = blockIdx.y, r = blockIdx.z, tid = threadIdx.x;
+    float *h = rir + (((long)r * S + s) * M + m) * Lr;
+    const int Td = (int)(tdiff[r] * fs);
+    if (Td >= Lr || t60[r] <= 0.0f) return;
+    const int W = min(Td, (int)(0.010f * fs));  // rms over the last 10 ms of the image-source part
+    float q = 0.0f;
+    for (int i = Td - W + tid; i < Td; i += 256) q += h[i] * h[i];
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float rms = W > 0 ? sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)W) : 0.0f;
+    const float decay = 6.9078f / (t60[r] * fs);
+    const uint32_t stream = synth_hash(seed ^ (uint32_t)((r * S + s) * M + m) * 0x9e3779b9U);
+    for (int n = Td + tid; n < Lr; n += 256) {
+        const float u = ((float)(synth_hash(stream + (uint32_t)n) >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+        const float xi = logf(u / (1.0f - u)) * 0.5513289f;  // logistic, variance (pi^2 / 3) * 0.5513^2 = 1
+        h[n] = rms * expf(-decay * (float)(n - Td)) * xi;
+    }
+}
+
 // one workgroup per (room, source, microphone): the RIR is accumulated in LDS with ds_add_f32, one image per thread at a time
 __global__ __launch_bounds__(1024) void k_rir_ism(RirArgs a) {
     extern __shared__ float h[];
@@ -201,6 +232,12 @@ int se_synth_rir(const float *room, const float *beta, const float *src, const f
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rir_ism), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * 4); attr = true; }
     hipLaunchKernelGGL(k_rir_ism, dim3(M, S, R), dim3(1024), (size_t)Lr * sizeof(float), static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : synth_fail("k_rir_ism launch failed");
+}
+
+int se_synth_rir_tail(float *rir, const float *tdiff, const float *t60, int R, int S, int M, int Lr, float fs, uint32_t seed, void *stream) {
+    if (!rir || !tdiff || !t60 || R <= 0 || S <= 0 || M <= 0 || Lr <= 0) return synth_fail("se_synth_rir_tail: bad argument");
+    hipLaunchKernelGGL(k_rir_tail, dim3(M, S, R), dim3(256), 0, static_cast<hipStream_t>(stream), rir, tdiff, t60, S, M, Lr, fs, seed);
+    return hipGetLastError() == hipSuccess ? SE_OK : synth_fail("se_synth_rir_tail: launch failed");
 }
 
 int se_synth_fir(const float *x, const float *rir, int R, int S, int M, int64_t L, int Lr, float *y, void *stream) {

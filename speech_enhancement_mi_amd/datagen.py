@@ -40,6 +40,8 @@ class RoomBatch:
     nb_img: Tuple[int, int, int]
     rir_len: int
     snr_db: np.ndarray = field(default=None)  # [R]
+    t60: np.ndarray = field(default=None)     # [R] seconds
+    tdiff: np.ndarray = field(default=None)   # [R] seconds: where gpuRIR switches from images to the diffuse tail (multichannel.py:46-52)
 
 
 class Single2Multi:
@@ -65,6 +67,7 @@ class Single2Multi:
         room = np.zeros((rooms, 3)); beta = np.zeros((rooms, 6)); src = np.zeros((rooms, S, 3)); mic = np.zeros((rooms, M, 3))
         nb = np.ones(3, np.int64)
         tmax = 0.1
+        t60s, tdiffs = np.zeros(rooms, np.float32), np.full(rooms, 0.1, np.float32)
         for r in range(rooms):
             room[r] = self._uniform(rng, *self.room_limit)
             t60 = rng.random() * (self.t60_limit[1] - self.t60_limit[0]) + self.t60_limit[0]
@@ -75,6 +78,7 @@ class Single2Multi:
                     tdiff = tm
                 nb = np.maximum(nb, t2n(tdiff, room[r]))
                 tmax = max(tmax, tm)
+                t60s[r], tdiffs[r] = t60, tdiff
             array = self._uniform(rng, *self.array_limit) * room[r]
             for m in range(M):
                 mic[r, m] = array + self._uniform(rng, *self.mic_limit)
@@ -84,19 +88,47 @@ class Single2Multi:
         rir_len = int(min(self.max_rir, math.ceil(tmax * self.fs)))
         snr = rng.random(rooms) * (snr_high - snr_low) + snr_low
         return RoomBatch(room.astype(np.float32), beta.astype(np.float32), src.astype(np.float32), mic.astype(np.float32), nb, rir_len,
-                         snr.astype(np.float32))
+                         snr.astype(np.float32), t60s, tdiffs)
 
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError(self.lib.se_synth_last_error().decode())
 
-    def rir(self, rb: RoomBatch, device="cuda") -> torch.Tensor:
-        """[R][S][M][rir_len] image-source RIRs on the GPU."""
+    @staticmethod
+    def _upload(rb: RoomBatch, device):
+        """All per-room scalars in ONE pinned host buffer and ONE asynchronous copy (six pageable copies = six host stalls per batch)."""
+        cached = getattr(rb, "_dev", None)
+        if cached is not None and cached[0] == str(device):
+            return cached[1]
+        parts = [rb.room, rb.beta, rb.src, rb.mic, rb.snr_db if rb.snr_db is not None else np.zeros(len(rb.room), np.float32),
+                 rb.tdiff if rb.tdiff is not None else np.zeros(len(rb.room), np.float32), rb.t60 if rb.t60 is not None else np.zeros(len(rb.room), np.float32)]
+        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in parts])
+        host = torch.from_numpy(flat).pin_memory()
+        dev = host.to(device, non_blocking=True)
+        out, off = [], 0
+        for a in parts:
+            n = int(np.asarray(a).size)
+            out.append(dev[off:off + n])
+            off += n
+        rb._dev = (str(device), (out, host))  # keep the pinned buffer alive until the copy has run
+        return rb._dev[1]
+
+    def rir(self, rb: RoomBatch, device="cuda", diffuse=False, seed=0) -> torch.Tensor:
+        """[R][S][M][rir_len] image-source RIRs on the GPU.  diffuse=True: beyond each room's Tdiff the response is replaced by the
+        stochastic exponentially decaying tail of se_synth_rir_tail (gpuRIR's second stage; PARITY UNPINNED, see csrc/se_synth.hip)."""
         R, S, M = rb.src.shape[0], rb.src.shape[1], rb.mic.shape[1]
-        dev = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (rb.room, rb.beta, rb.src, rb.mic)]
+        if rb.rir_len > 36 * 1024:
+            raise RuntimeError("RIR longer than 36864 samples does not fit the LDS accumulator")
+        (dev, _host) = self._upload(rb, device)
         out = torch.empty(R, S, M, rb.rir_len, device=device, dtype=torch.float32)
-        self._check(self.lib.se_synth_rir(*[C.c_void_p(t.data_ptr()) for t in dev], R, S, M, *rb.nb_img, float(self.fs), SOUND_SPEED, rb.rir_len,
+        self._check(self.lib.se_synth_rir(*[C.c_void_p(t.data_ptr()) for t in dev[:4]], R, S, M, *rb.nb_img, float(self.fs), SOUND_SPEED, rb.rir_len,
                                           C.c_void_p(out.data_ptr()), Engine._stream()))
+        if diffuse:
+            if rb.tdiff is None or rb.t60 is None:
+                raise ValueError("this RoomBatch carries no t60 / tdiff (sample() fills them)")
+            td, t6 = dev[5], dev[6]
+            self._check(self.lib.se_synth_rir_tail(C.c_void_p(out.data_ptr()), C.c_void_p(td.data_ptr()), C.c_void_p(t6.data_ptr()), R, S, M, rb.rir_len,
+                                                   float(self.fs), int(seed) & 0xFFFFFFFF, Engine._stream()))
         return out
 
     def simulate(self, sources: torch.Tensor, rb: RoomBatch, rir: torch.Tensor = None):
@@ -113,7 +145,71 @@ class Single2Multi:
         mix = torch.empty(R, M, L, device=sources.device, dtype=torch.float32)
         noise = torch.empty_like(mix)
         absmax = torch.empty(R, M, device=sources.device, dtype=torch.float32)
-        snr = torch.from_numpy(rb.snr_db).to(sources.device)
+        snr = self._upload(rb, sources.device)[0][4]
         self._check(self.lib.se_synth_mix(C.c_void_p(y.data_ptr()), C.c_void_p(snr.data_ptr()), R, S, M, L, MAX_AMP, C.c_void_p(mix.data_ptr()),
                                           C.c_void_p(noise.data_ptr()), C.c_void_p(absmax.data_ptr()), st))
         return mix, y, noise
+
+
+    def simulate_reference(self, sources, aug_sources=None, noise=False, RIR=None, rng=None, diffuse=False):
+        """The reference's call shape (multichannel.py:37-103) for ONE room: `sources` / `aug_sources` = lists of num_src 1-D
+        signals -> (multichannel, aug_multichannel[, RIR]) as lists of [M, L] tensors; with `RIR` given, `sources` is one noise
+        signal convolved with it (the reference's AddNoise path, augment.py:51-53).  Built on the batched kernels with R = 1; the
+        tensors stay on the GPU (the reference returns CPU tensors)."""
+        dev = "cuda"
+        as_t = lambda v: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))).to(dev, torch.float32).reshape(-1)
+        if RIR is not None:
+            x = as_t(sources)
+            y = torch.empty(1, 1, RIR.shape[-2], x.numel(), device=dev)
+            self._check(self.lib.se_synth_fir(C.c_void_p(x.data_ptr()), C.c_void_p(RIR.data_ptr()), 1, 1, RIR.shape[-2], x.numel(), RIR.shape[-1],
+                                              C.c_void_p(y.data_ptr()), Engine._stream()))
+            return y[0, 0]
+        rb = self.sample(1, rng or np.random.default_rng())
+        rir = self.rir(rb, dev, diffuse=diffuse)                      # [1][num_src + 1][M][Lr]; the last source position is the noise's
+        outs = []
+        for group in (sources, aug_sources):
+            res = []
+            for i, sig in enumerate(group or []):
+                x = as_t(sig)
+                y = torch.empty(1, 1, self.num_mic, x.numel(), device=dev)
+                h = rir[:, i:i + 1].contiguous()
+                self._check(self.lib.se_synth_fir(C.c_void_p(x.data_ptr()), C.c_void_p(h.data_ptr()), 1, 1, self.num_mic, x.numel(), rb.rir_len,
+                                                  C.c_void_p(y.data_ptr()), Engine._stream()))
+                res.append(y[0, 0])
+            outs.append(res)
+        if noise:
+            return outs[0], outs[1], rir[:, self.num_src:self.num_src + 1].contiguous()
+        return outs[0], outs[1]
+
+
+class ChunkChain:
+    """data_c.LibriPartyDataset's chunk buffer (data_c.py:60-84, 155-173), restated with its quirks: a mixed utterance is cut into
+    chunks of random length l ~ U{16000 .. max_length - 1}; the cursor advances by `start += end` (not `start = end`: after the second
+    chunk material is skipped), a remainder shorter than one second ends the cut; get_buffer POPS FROM THE END, so the chunks of one
+    utterance are served last-first, the first pop after a refill with flag=False and every further pop with flag=True (the model
+    then continues its state across chunks that are not adjacent in time - reproduced as is)."""
+
+    def __init__(self, make_utterance, max_length=60000, rng=None):
+        self.make_utterance, self.max_length = make_utterance, int(max_length)
+        self.rng = rng or np.random.default_rng()
+        self.buffer = []
+
+    def set_buffer(self, mix, source, noise, length):
+        start, lens = 0, mix.shape[-1]
+        while start < lens:
+            l = int(self.rng.integers(16000, self.max_length))
+            end = min(lens, start + l)
+            if end - start < 16000:
+                break
+            self.buffer.append((mix[..., start:end], source[..., start:end], noise[..., start:end], end - start))
+            start += end
+
+    def __next__(self):
+        flag = len(self.buffer) > 0
+        while len(self.buffer) == 0:
+            self.set_buffer(*self.make_utterance())
+        mix, source, noise, length = self.buffer.pop()
+        return dict(mix=mix, source=source, noise=noise, length=length, flag=flag)
+
+    def __iter__(self):
+        return self

@@ -26,7 +26,7 @@ EXPORTS = [
     "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd",
     "se_sig_create", "se_sig_destroy", "se_sig_stft", "se_sig_istft", "se_train_ola_fwd", "se_train_ola_bwd", "se_train_feat", "se_train_mask_fwd",
     "se_train_mask_bwd", "se_train_gln_fwd", "se_train_gln_bwd", "se_train_colsum", "se_train_colsum_tall", "se_train_skip_fwd", "se_train_skip_bwd",
-    "se_train_add", "se_train_add3", "se_train_gate_fwd", "se_train_gate_bwd", "se_train_elu_bwd", "se_train_pre5", "se_train_gru_hprev", "se_train_conv_ws_floats", "se_train_conv_w", "se_train_conv_wgrad_det", "se_train_gemm_tn_det", "se_synth_last_error", "se_synth_rir", "se_synth_fir", "se_synth_mix",
+    "se_train_add", "se_train_add3", "se_train_gate_fwd", "se_train_gate_bwd", "se_train_elu_bwd", "se_train_pre5", "se_train_gru_hprev", "se_train_conv_ws_floats", "se_train_conv_w", "se_train_conv_wgrad_det", "se_train_gemm_tn_det", "se_synth_last_error", "se_synth_rir", "se_synth_rir_tail", "se_synth_fir", "se_synth_mix",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     L.se_train_gemm_tn_det.argtypes = [vp, vp, vp, C.POINTER(C.c_int), i64, i32, i32, vp]
     L.se_synth_last_error.restype = C.c_char_p
     L.se_synth_rir.argtypes = [vp, vp, vp, vp] + [i32] * 6 + [C.c_float, C.c_float, i32, vp, vp]
+    L.se_synth_rir_tail.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, C.c_uint32, vp]
     L.se_synth_fir.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp, vp]
     L.se_synth_mix.argtypes = [vp, vp, i32, i32, i32, i64, C.c_float, vp, vp, vp, vp]
     L.se_profile.argtypes = [vp, C.c_int]

@@ -239,6 +239,28 @@ def image_rir(room, beta, src, mic, nb_img, fs=16000.0, c=343.0, length=4096):
     return h.astype(np.float32)
 
 
+def _hash32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
+def diffuse_tail(h: np.ndarray, tdiff: float, t60: float, fs: float, seed: int, rir_index: int) -> np.ndarray:
+    """numpy restatement of k_rir_tail (csrc/se_synth.hip): h[n >= Td] <- rms(h[Td-W:Td]) * exp(-6.9078 (n-Td) / (T60 fs)) * logistic noise."""
+    h = np.array(h, dtype=np.float32)
+    Lr, Td = h.shape[0], int(np.float32(tdiff) * np.float32(fs))
+    if Td >= Lr or t60 <= 0:
+        return h
+    W = min(Td, int(0.010 * fs))
+    rms = np.sqrt(np.sum(h[Td - W:Td].astype(np.float64) ** 2) / W) if W > 0 else 0.0
+    stream = _hash32((seed & 0xFFFFFFFF) ^ ((rir_index * 0x9e3779b9) & 0xFFFFFFFF))
+    n = np.arange(Td, Lr, dtype=np.uint64)
+    u = ((_hash32((stream + n) & 0xFFFFFFFF) >> 8).astype(np.float64) + 0.5) / 16777216.0
+    xi = np.log(u / (1.0 - u)) * 0.5513289
+    h[Td:] = (rms * np.exp(-(6.9078 / (t60 * fs)) * (n - Td).astype(np.float64)) * xi).astype(np.float32)
+    return h
+
+
 def fir_filter(x: np.ndarray, h: np.ndarray) -> np.ndarray:
     """y[n] = sum_k h[k] x[n - k], truncated to len(x) (gpuRIR.simulateTrajectory of a static source)."""
     from scipy.signal import fftconvolve

@@ -84,3 +84,80 @@ def test_gpu_generator_rejects_host_tensors_and_long_rirs():
     rb.rir_len = 40000
     with pytest.raises(RuntimeError):
         sim.rir(rb)
+
+
+def test_chunk_chain_reproduces_the_reference_buffer_semantics():
+    """data_c.py:60-84,155-173: random 1..3.75 s chunks cut with `start += end`, served LAST FIRST, flag=False only for the first
+    pop after a refill."""
+    from speech_enhancement_mi_amd.datagen import ChunkChain
+    lens = iter([200000, 50000, 15000, 70000])
+    made = []
+
+    def make():
+        L = next(lens)
+        made.append(L)
+        base = np.arange(L, dtype=np.float32)
+        return base[None, :].repeat(3, 0), base[None, None, :], base[None, :] * 0, L
+
+    chain = ChunkChain(make, max_length=60000, rng=np.random.default_rng(5))
+    # restate the cut with the same generator stream
+    rng = np.random.default_rng(5)
+    expect = []
+    for L in (200000, 50000):
+        chunks, start = [], 0
+        while start < L:
+            l = int(rng.integers(16000, 60000))
+            end = min(L, start + l)
+            if end - start < 16000:
+                break
+            chunks.append((start, end))
+            start += end
+        expect.append(chunks)
+    assert len(expect[0]) >= 2 and expect[0][1][0] == expect[0][0][1]            # second chunk starts where the first ended ...
+    if len(expect[0]) > 2:
+        assert expect[0][2][0] == expect[0][1][0] + expect[0][1][1]              # ... the third one skips material (start += end)
+    got = []
+    for chunks in expect:
+        for k, (s0, e0) in enumerate(reversed(chunks)):
+            item = next(chain)
+            assert item["flag"] == (k > 0)
+            assert item["length"] == e0 - s0 and item["mix"].shape == (3, e0 - s0)
+            assert item["mix"][0, 0] == s0 and item["source"][0, 0, -1] == e0 - 1
+            got.append(item)
+    assert made == [200000, 50000]
+    # an utterance too short for one chunk is skipped by the refill loop (15000 < 16000), the next one is used
+    item = next(chain)
+    assert made == [200000, 50000, 15000, 70000] and item["flag"] is False
+
+
+@pytest.mark.gpu
+def test_gpu_diffuse_tail_and_reference_shaped_simulate():
+    """se_synth_rir_tail (gpuRIR's second stage, PARITY UNPINNED) against its numpy restatement; the image-source part before Tdiff is
+    untouched; the tail decays by 60 dB per T60.  simulate_reference keeps the reference's list-in / list-out call shape."""
+    import torch
+    from speech_enhancement_mi_amd.datagen import Single2Multi
+    sim = Single2Multi(ROOM, (0.3, 0.5), BETA, ARRAY, MIC, SOURCE, num_src=1, num_mic=3, max_images=(8, 8, 6), max_rir=9000)
+    rb = sim.sample(2, np.random.default_rng(7))
+    plain = sim.rir(rb).cpu().numpy()
+    tail = sim.rir(rb, diffuse=True, seed=123).cpu().numpy()
+    R, S, M = 2, 2, 3
+    for r in range(R):
+        td = int(np.float32(rb.tdiff[r]) * np.float32(16000.0))
+        assert 0 < td < rb.rir_len
+        for s_ in range(S):
+            for m in range(M):
+                assert rel(tail[r, s_, m, :td], plain[r, s_, m, :td]) < 1e-5   # (two launches: the LDS float adds of the image sum reorder)
+                ref = synth.diffuse_tail(plain[r, s_, m], rb.tdiff[r], rb.t60[r], 16000.0, 123, (r * S + s_) * M + m)
+                assert rel(tail[r, s_, m, td:], ref[td:]) < 1e-3, (r, s_, m)
+        # envelope: energy of the tail's second half-T60 vs the first half-T60 ~ -30 dB
+        h = tail[r, 0, 0].astype(np.float64)
+        n = int(rb.t60[r] * 16000 / 2)
+        if td + 2 * n <= rb.rir_len:
+            db = 10 * np.log10((h[td + n:td + 2 * n] ** 2).sum() / (h[td:td + n] ** 2).sum())
+            assert -36 < db < -24, db
+    x, _ = synth.synth_utterances(1, 8000, 1, seed=2)
+    multi, aug, rir = sim.simulate_reference([torch.from_numpy(x[0, 0])], [torch.from_numpy(x[0, 0] * 0.5)], noise=True, rng=np.random.default_rng(3))
+    assert len(multi) == 1 and len(aug) == 1 and multi[0].shape == (3, 8000) and multi[0].is_cuda
+    assert rel(aug[0].cpu().numpy(), 0.5 * multi[0].cpu().numpy()) < 1e-5
+    nm = sim.simulate_reference(torch.randn(8000), RIR=rir)
+    assert nm.shape == (3, 8000) and bool(torch.isfinite(nm).all())
