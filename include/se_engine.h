@@ -91,6 +91,14 @@ int se_step(se_engine *e, const float *wav_in, float *wav_out, void *stream);
 int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t length, int flag,
                         float *out, void *stream);
 
+/* Ragged batch (the reference's utterances are 1 .. 3.75 s long, data_c.py:155-173): stream b holds lengths[b] <= max_length valid
+ * samples of mixture [B, M, max_length]; every stream gets exactly the output it would get alone - its own zero padding (samples past
+ * its length read as zeros) and out[b, lengths[b]:] = 0.  lengths is a HOST array.  The batch still runs max-length segments: a stream
+ * that has ended keeps its slot busy until the call ends (no compaction), and its carried state has then also seen those zero segments:
+ * follow with flag = 0, or se_reset_stream, for streams that ended early. */
+int se_realtime_process_ragged(se_engine *e, const float *mixture, int batch, int64_t max_length, const int64_t *lengths_host, int flag, float *out,
+                               void *stream);
+
 /* Per-stage entry points (parity tests; same arithmetic as inside se_step).
  * se_stft:    stft_trans  (CRN.py:505-512): seg [n, K] -> spec [n, F, T, 2]   (n = B*M rows)
  * se_istft:   istft_trans (CRN.py:514-520): spec [n, F, T, 2] -> wav [n, K]
@@ -211,8 +219,8 @@ int se_train_gru_seq_bwd(const float *dout, const float *dhT, const float *gates
  * registers and exchange the state vector per step through write-through stores + an agent-scope arrival counter.
  * Replaces T dependent step launches (round 2) for micro-batches of up to 32 streams.  Rows of gi / out / gates / dout / dgi /
  * dgh are addressed as row(b, s) = (s / Tseg) * ldN + b * ldB + s % Tseg, which covers [B][T] (Tseg = T, ldN = 0, ldB = T) and
- * the training forward's segment-major [N][B][Tseg] (ldN = B * Tseg, ldB = Tseg).  scratch: 16 + 2 * B * H floats (forward),
- * 16 + 6 * B * H floats (backward); word [1] of scratch is non-zero after a bounded-spin timeout (results invalid).
+ * the training forward's segment-major [N][B][Tseg] (ldN = B * Tseg, ldB = Tseg).  scratch: 16 + 4 * B * H floats (forward),
+ * 16 + 12 * B * H floats (backward) - the state vector travels as 8-byte {step tag, value} granules; word [1] of scratch is non-zero after a bounded-spin timeout (results invalid).
  * gates may be NULL in the forward (inference / no_grad).  seg_len as in se_train_gru_seq_bwd. */
 int se_train_gru_pseq_supported(int B, int H);
 int se_train_gru_pseq_fwd(const float *gi, const float *h0, const float *whh, const float *bhh, float *out, float *gates, float *hT,

@@ -149,9 +149,11 @@ class TemporalCRN(nn.Module):
             eng.reset(x.shape[0])  # lazy state allocation on first call, CRN.py:325-326
         return eng.forward(x.contiguous().float())
 
-    def realtime_process(self, mixture, flag=False):
+    def realtime_process(self, mixture, flag=False, lengths=None):
+        """lengths: extension over the reference - a ragged batch (zero-padded to the longest utterance): every stream is processed as if
+        alone with its own length (own padding; zeros beyond its length in the output)."""
         eng = self._engine_for(mixture)
-        return eng.realtime_process(mixture.contiguous().float(), flag=bool(flag))
+        return eng.realtime_process(mixture.contiguous().float(), flag=bool(flag), lengths=lengths)
 
     def compute_loss(self, source, pred_source, length):
         """loss = 0.7 * stoi_loss + 0.3 * (-SI-SNR), NaN -> zeros  (CRN.py:593-617); returns (loss, stoi, sisnr) on the

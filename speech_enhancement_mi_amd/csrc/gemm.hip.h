@@ -286,7 +286,9 @@ struct GemmPArgs {
     int relu;
     unsigned a_bytes, w_bytes;  // buffer ranges
     int nrt, nct;      // row / column tiles
-    int gx, gy;        // XCD grid (gx * gy = 8, nrt % gx == 0, nct % gy == 0) or gx = 0: plain row-major tile order
+    int gx, gy;        // XCD grid (gx * gy = 8, nrt % gx == 0, nct % gy == 0); gx = 0: plain row-major tile order; gx = -1: banded -
+                       // XCD x (= block id mod 8) owns the gy consecutive tiles [x * gy, (x + 1) * gy) of the row-major order (a band
+                       // of rows: A is fetched by one L2 apart from the band seams), for tile grids no equal 8-block split divides
 };
 
 constexpr int kGemmPBM = 256, kGemmPBN = 128;
@@ -307,7 +309,12 @@ __global__ __launch_bounds__(512) void k_gemm_p(GemmPArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     int rt, ct;
-    if (a.gx) {
+    if (a.gx < 0) {
+        const int t = (blockIdx.x & 7) * a.gy + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= a.gy || t >= a.nrt * a.nct) return;  // (uniform per workgroup, ahead of every barrier)
+        rt = t / a.nct;
+        ct = t - rt * a.nct;
+    } else if (a.gx) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int br = a.nrt / a.gx, bc = a.nct / a.gy;  // tiles per XCD block
         rt = (xcd / a.gy) * br + slot / bc;

@@ -60,11 +60,10 @@ __device__ __forceinline__ long pseq_row(int b, int s, int Tseg, long ldN, long 
     return (long)n * ldN + (long)b * ldB + (s - n * Tseg);
 }
 
-// one lane: arrive, then wait until `target` arrivals are visible (bounded).  Returns false on timeout.
-__device__ __forceinline__ bool pseq_arrive_and_wait(unsigned *sync, unsigned target, bool wait) {
+// one lane: arrive / wait until `target` arrivals are visible (bounded; returns false on timeout)
+__device__ __forceinline__ void pseq_arrive(unsigned *sync) { __hip_atomic_fetch_add((pgu32 *)sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool pseq_wait(unsigned *sync, unsigned target) {
     pgu32 *cnt = (pgu32 *)sync;
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!wait) return true;
     const long long t0 = wall_clock64();
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -115,19 +114,28 @@ __global__ __launch_bounds__(512) void k_gru_pseq_fwd(GruPseqFwdArgs a) {
                 hown[mt][r] = row < B ? a.h0[(long)row * H + u0 + l15] : 0.0f;
             }
     }
+    // gate pre-activations: independent of the recurrence, fetched ONE STEP AHEAD (every step touches new rows: an HBM round trip that
+    // would otherwise sit on the step's critical path)
+    float gir[MT][4], giz[MT][4], gin[MT][4], nir[MT][4], niz[MT][4], nin[MT][4];
+    auto fetch_gi = [&](int s, float (&xr)[MT][4], float (&xz)[MT][4], float (&xn)[MT][4]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = min(mt * 16 + kq * 4 + r, B - 1);
+                const float *g = a.gi + pseq_row(row, s, a.Tseg, a.ldN, a.ldB) * 3 * H + u0 + l15;
+                xr[mt][r] = g[0]; xz[mt][r] = g[H]; xn[mt][r] = g[2 * H];
+            }
+    };
+    if (wave == 0) fetch_gi(0, nir, niz, nin);
     __syncthreads();
     for (int s = 0; s < a.T; s++) {
-        // gate pre-activations of this step: independent of the recurrence, issued before the contraction
-        float gir[MT][4], giz[MT][4], gin[MT][4];
         if (wave == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = min(mt * 16 + kq * 4 + r, B - 1);
-                    const float *g = a.gi + pseq_row(row, s, a.Tseg, a.ldN, a.ldB) * 3 * H + u0 + l15;
-                    gir[mt][r] = g[0]; giz[mt][r] = g[H]; gin[mt][r] = g[2 * H];
-                }
+                for (int r = 0; r < 4; r++) { gir[mt][r] = nir[mt][r]; giz[mt][r] = niz[mt][r]; gin[mt][r] = nin[mt][r]; }
+            if (s + 1 < a.T) fetch_gi(s + 1, nir, niz, nin);
         }
         pf32x4 acc[MT][3];
 #pragma unroll
@@ -171,6 +179,8 @@ __global__ __launch_bounds__(512) void k_gru_pseq_fwd(GruPseqFwdArgs a) {
         __syncthreads();
         if (wave == 0) {
             const int nw = blockDim.x >> 6;
+            float vr[MT][4], vz[MT][4], vn[MT][4], vg[MT][4];
+            // (1) the new state of this workgroup's units, published FIRST: the other workgroups wait for nothing else
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -178,27 +188,36 @@ __global__ __launch_bounds__(512) void k_gru_pseq_fwd(GruPseqFwdArgs a) {
                     const int row = mt * 16 + kq * 4 + r;
                     float p0 = acc[mt][0][r], p1 = acc[mt][1][r], p2 = acc[mt][2][r];
                     for (int wv = 1; wv < nw; wv++) { p0 += red[wv][mt][0][r][lane]; p1 += red[wv][mt][1][r][lane]; p2 += red[wv][mt][2][r][lane]; }
-                    if (row < B) {
-                        const float gh_n = p2 + bh[2];
-                        const float rg = 1.0f / (1.0f + expf(-(gir[mt][r] + p0 + bh[0])));
-                        const float zg = 1.0f / (1.0f + expf(-(giz[mt][r] + p1 + bh[1])));
-                        const float ng = tanhf(gin[mt][r] + rg * gh_n);
-                        const float hn = (1.0f - zg) * ng + zg * hown[mt][r];
-                        hown[mt][r] = hn;
-                        const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
-                        a.out[ro * H + u0 + l15] = hn;
-                        if (a.gates) {
-                            float *gs = a.gates + ro * 4 * H + u0 + l15;
-                            gs[0] = rg; gs[H] = zg; gs[2 * H] = ng; gs[3 * H] = gh_n;
-                        }
-                        if (s + 1 < a.T) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rs, (((s & 1) * B + row) * H + u0 + l15) * 4, 0, 16);  // sc1
-                        else a.hT[(long)row * H + u0 + l15] = hn;
-                    }
+                    const float gh_n = p2 + bh[2];
+                    const float rg = 1.0f / (1.0f + expf(-(gir[mt][r] + p0 + bh[0])));
+                    const float zg = 1.0f / (1.0f + expf(-(giz[mt][r] + p1 + bh[1])));
+                    const float ng = tanhf(gin[mt][r] + rg * gh_n);
+                    const float hn = (1.0f - zg) * ng + zg * hown[mt][r];
+                    hown[mt][r] = hn;
+                    vr[mt][r] = rg; vz[mt][r] = zg; vn[mt][r] = ng; vg[mt][r] = gh_n;
+                    if (row < B && s + 1 < a.T)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rs, (((s & 1) * B + row) * H + u0 + l15) * 4, 0, 16);  // sc1
                 }
             if (s + 1 < a.T) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the only storing wave drains before it signals
-                if (lane == 0 && !pseq_arrive_and_wait(a.sync, NWG * (unsigned)(s + 1), true)) s_fail = 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the only storing wave drains its write-through stores before it signals
+                if (lane == 0) pseq_arrive(a.sync);
             }
+            // (2) the step's outputs for later kernels (plain stores, off the exchange's critical path)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    if (row >= B) continue;
+                    const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
+                    a.out[ro * H + u0 + l15] = hown[mt][r];
+                    if (a.gates) {
+                        float *gs = a.gates + ro * 4 * H + u0 + l15;
+                        gs[0] = vr[mt][r]; gs[H] = vz[mt][r]; gs[2 * H] = vn[mt][r]; gs[3 * H] = vg[mt][r];
+                    }
+                    if (s + 1 == a.T) a.hT[(long)row * H + u0 + l15] = hown[mt][r];
+                }
+            if (s + 1 < a.T && lane == 0 && !pseq_wait(a.sync, NWG * (unsigned)(s + 1))) s_fail = 1;
         }
         __syncthreads();
         if (s_fail) break;  // uniform
@@ -237,6 +256,24 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
             dhz[mt][r] = (wave == 0 && a.dhT && row < B) ? a.dhT[(long)row * H + u0 + l15] : 0.0f;
             gown[mt][r] = 0.0f;
         }
+    // the step's saved forward values (dout, r, z, n, gh_n, h_{s-1}) are fetched ONE STEP AHEAD: new rows every step = an HBM round trip
+    // that would otherwise open every step
+    float pin[MT][4][6], nin6[MT][4][6], vo[MT][4][4];
+    auto fetch_in = [&](int s, float (&x)[MT][4][6]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = min(mt * 16 + kq * 4 + r, B - 1);
+                const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
+                const int u = u0 + l15;
+                const float *g = a.gates + ro * 4 * H + u;
+                x[mt][r][0] = a.dout[ro * H + u];
+                x[mt][r][1] = g[0]; x[mt][r][2] = g[H]; x[mt][r][3] = g[2 * H]; x[mt][r][4] = g[3 * H];
+                x[mt][r][5] = s == 0 ? a.h0[(long)row * H + u] : a.out[pseq_row(row, s - 1, a.Tseg, a.ldN, a.ldB) * H + u];
+            }
+    };
+    if (wave == 0) fetch_in(a.T - 1, nin6);
     __syncthreads();
     for (int s = a.T - 1; s >= 0; s--) {
         const int it = a.T - 1 - s;
@@ -245,25 +282,29 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) pin[mt][r][k] = nin6[mt][r][k];
+            if (s > 0) fetch_in(s - 1, nin6);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = mt * 16 + kq * 4 + r;
                     if (row >= B) continue;
                     const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
                     const int u = u0 + l15;
-                    float dh = a.dout[ro * H + u];
+                    float dh = pin[mt][r][0];
                     if (!cut) dh += dhz[mt][r] + gown[mt][r];
-                    const float *g = a.gates + ro * 4 * H + u;
-                    const float rg = g[0], zg = g[H], ng = g[2 * H], ghn = g[3 * H];
-                    const float hp = s == 0 ? a.h0[(long)row * H + u] : a.out[pseq_row(row, s - 1, a.Tseg, a.ldN, a.ldB) * H + u];
+                    const float rg = pin[mt][r][1], zg = pin[mt][r][2], ng = pin[mt][r][3], ghn = pin[mt][r][4];
+                    const float hp = pin[mt][r][5];
                     const float dn = dh * (1.0f - zg), dz = dh * (hp - ng);
                     const float da = dn * (1.0f - ng * ng);
                     const float dzp = dz * zg * (1.0f - zg);
                     const float drp = da * ghn * rg * (1.0f - rg);
-                    float *gi = a.dgi + ro * K3 + u, *gh = a.dgh + ro * K3 + u;
-                    gi[0] = drp; gi[H] = dzp; gi[2 * H] = da;
-                    gh[0] = drp; gh[H] = dzp; gh[2 * H] = da * rg;
                     dhz[mt][r] = dh * zg;
-                    if (s > 0) {
+                    vo[mt][r][0] = drp; vo[mt][r][1] = dzp; vo[mt][r][2] = da; vo[mt][r][3] = da * rg;
+                    if (s > 0) {  // published first: the other workgroups wait for nothing else
                         const int off = (((s & 1) * B + row) * K3 + u) * 4;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, drp), rs, off, 0, 16);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dzp), rs, off + H * 4, 0, 16);
@@ -272,8 +313,20 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
                 }
             if (s > 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0 && !pseq_arrive_and_wait(a.sync, NWG * (unsigned)(it + 1), true)) s_fail = 1;
+                if (lane == 0) pseq_arrive(a.sync);
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    if (row >= B) continue;
+                    const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
+                    float *gi = a.dgi + ro * K3 + u0 + l15, *gh = a.dgh + ro * K3 + u0 + l15;
+                    gi[0] = vo[mt][r][0]; gi[H] = vo[mt][r][1]; gi[2 * H] = vo[mt][r][2];
+                    gh[0] = vo[mt][r][0]; gh[H] = vo[mt][r][1]; gh[2 * H] = vo[mt][r][3];
+                }
+            if (s > 0 && lane == 0 && !pseq_wait(a.sync, NWG * (unsigned)(it + 1))) s_fail = 1;
         }
         if (s == 0) break;  // uniform
         __syncthreads();
@@ -318,6 +371,265 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
         }
         // the other waves may not overwrite `red` before wave 0 has read it: they next write it after the NEXT step's first
         // barrier, which wave 0 only reaches after these reads
+    }
+}
+
+
+// ---- granule exchange (cdna_hip_programming.md Guideline 16, R2: "the data IS the flag") ------------------------------------------------
+// The counter form above pays, per step: the producer's store drain (s_waitcnt vmcnt(0) behind write-through stores), an atomic arrival,
+// a poll round trip, and only then the consumers' loads - 7.2 / 8.2 us per forward / backward step.  Here every exchanged value travels as
+// ONE aligned 8-byte granule {tag = step epoch, value} written by one sc1 store; a consumer wave simply re-reads the granules it needs
+// (16-byte sc1 loads = two granules) until every tag shows the epoch it waits for: no drain, no counter, no separate poll.
+// Ping-pong safety: a producer can write epoch e + 2 into a buffer only after every workgroup has produced epoch e + 1, which each does
+// after its waves consumed epoch e from that buffer.  The exchange buffer is zeroed by the host before every launch (epochs start at 1).
+typedef __attribute__((address_space(1))) unsigned long long pgu64;
+
+template <int KJ>
+__device__ __forceinline__ bool pseq_gather(const __amdgpu_buffer_rsrc_t rs, int off_bytes, unsigned epoch, float (&av)[KJ], unsigned *sync, int *s_fail) {
+    // granules are handled as 64-bit words {tag : value}: (hipcc 7.2 folded `q[2]` of a 4 x u32 view of the 16-byte load into `q[0]` at the
+    // loop exit - every odd granule came back as its even neighbour; the u64 form below compiles to what it says)
+    typedef unsigned long long pu64x2 __attribute__((ext_vector_type(2)));
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    pu64x2 q[KJ / 2];
+    bool done = false;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < KJ / 2; j++) {
+            q[j] = __builtin_bit_cast(pu64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, off_bytes + j * 16, 0, 16));  // sc1: two granules
+            ok = ok && (unsigned)(q[j][0] >> 32) == epoch && (unsigned)(q[j][1] >> 32) == epoch;
+        }
+        if (__all(ok)) { done = true; break; }
+        if ((++spins & 31u) == 0) {
+            if (*s_fail || wall_clock64() - t0 > kPseqSpinLimit) {
+                *s_fail = 1;
+                __hip_atomic_store((pgu32 *)sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KJ / 2; j++) {
+        av[2 * j] = __builtin_bit_cast(float, (unsigned)(q[j][0] & 0xffffffffULL));
+        av[2 * j + 1] = __builtin_bit_cast(float, (unsigned)(q[j][1] & 0xffffffffULL));
+    }
+    return done;
+}
+
+template <int KJ, int MT>
+__global__ __launch_bounds__(512) void k_gru_gseq_fwd(GruPseqFwdArgs a) {
+    __shared__ float red[8][MT][3][4][64];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int H = a.H, B = a.B, u0 = blockIdx.x * 16;
+    const int kbase = wave * 4 * KJ + kq * KJ;
+    if (tid == 0) s_fail = 0;
+    float w[3][KJ];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float *wp = a.whh + ((long)g * H + u0 + l15) * H + kbase;
+#pragma unroll
+        for (int j = 0; j < KJ; j += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(wp + j);
+            w[g][j] = q.x; w[g][j + 1] = q.y; w[g][j + 2] = q.z; w[g][j + 3] = q.w;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (int)(2L * B * H * 8), 0x00020000);  // granules [2][B][H]
+    float hown[MT][4], bh[3];
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) bh[g] = a.bhh[g * H + u0 + l15];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = mt * 16 + kq * 4 + r;
+                hown[mt][r] = row < B ? a.h0[(long)row * H + u0 + l15] : 0.0f;
+            }
+    }
+    __syncthreads();
+    for (int s = 0; s < a.T; s++) {
+        float gir[MT][4], giz[MT][4], gin[MT][4];
+        if (wave == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = min(mt * 16 + kq * 4 + r, B - 1);
+                    const float *g = a.gi + pseq_row(row, s, a.Tseg, a.ldN, a.ldB) * 3 * H + u0 + l15;
+                    gir[mt][r] = g[0]; giz[mt][r] = g[H]; gin[mt][r] = g[2 * H];
+                }
+        }
+        pf32x4 acc[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int g = 0; g < 3; g++) acc[mt][g] = pf32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int arow = min(mt * 16 + l15, B - 1);
+            float av[KJ];
+            if (s == 0) {
+                const float *hp = a.h0 + (long)arow * H + kbase;
+#pragma unroll
+                for (int j = 0; j < KJ; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(hp + j);
+                    av[j] = q.x; av[j + 1] = q.y; av[j + 2] = q.z; av[j + 3] = q.w;
+                }
+            } else {
+                pseq_gather<KJ>(rs, ((((s - 1) & 1) * B + arow) * H + kbase) * 8, (unsigned)s, av, a.sync, &s_fail);
+            }
+#pragma unroll
+            for (int j = 0; j < KJ; j++) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[0][j], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[1][j], acc[mt][1], 0, 0, 0);
+                acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[2][j], acc[mt][2], 0, 0, 0);
+            }
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) red[wave][mt][g][r][lane] = acc[mt][g][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int nw = blockDim.x >> 6;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    float p0 = acc[mt][0][r], p1 = acc[mt][1][r], p2 = acc[mt][2][r];
+                    for (int wv = 1; wv < nw; wv++) { p0 += red[wv][mt][0][r][lane]; p1 += red[wv][mt][1][r][lane]; p2 += red[wv][mt][2][r][lane]; }
+                    if (row < B) {
+                        const float gh_n = p2 + bh[2];
+                        const float rg = 1.0f / (1.0f + expf(-(gir[mt][r] + p0 + bh[0])));
+                        const float zg = 1.0f / (1.0f + expf(-(giz[mt][r] + p1 + bh[1])));
+                        const float ng = tanhf(gin[mt][r] + rg * gh_n);
+                        const float hn = (1.0f - zg) * ng + zg * hown[mt][r];
+                        hown[mt][r] = hn;
+                        if (s + 1 < a.T) {  // publish first: the other workgroups wait for exactly these granules
+                            pgu64 *gp = (pgu64 *)a.hx + ((long)(s & 1) * B + row) * H + u0 + l15;
+                            __hip_atomic_store(gp, ((unsigned long long)(unsigned)(s + 1) << 32) | __builtin_bit_cast(unsigned, hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else a.hT[(long)row * H + u0 + l15] = hn;
+                        const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
+                        a.out[ro * H + u0 + l15] = hn;
+                        if (a.gates) {
+                            float *gs = a.gates + ro * 4 * H + u0 + l15;
+                            gs[0] = rg; gs[H] = zg; gs[2 * H] = ng; gs[3 * H] = gh_n;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        if (s_fail) break;  // uniform
+    }
+}
+
+template <int KJ, int MT>
+__global__ __launch_bounds__(512) void k_gru_gseq_bwd(GruPseqBwdArgs a) {
+    __shared__ float red[8][MT][4][64];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int H = a.H, B = a.B, u0 = blockIdx.x * 16, K3 = 3 * H;
+    const int kbase = wave * 4 * KJ + kq * KJ;
+    if (tid == 0) s_fail = 0;
+    float w[3][KJ];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *wp = a.whh_t + (long)(u0 + l15) * K3 + c * H + kbase;
+#pragma unroll
+        for (int j = 0; j < KJ; j += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(wp + j);
+            w[c][j] = q.x; w[c][j + 1] = q.y; w[c][j + 2] = q.z; w[c][j + 3] = q.w;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.gx, 0, (int)(2L * B * K3 * 8), 0x00020000);  // granules [2][B][3H]
+    float dhz[MT][4], gown[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = mt * 16 + kq * 4 + r;
+            dhz[mt][r] = (wave == 0 && a.dhT && row < B) ? a.dhT[(long)row * H + u0 + l15] : 0.0f;
+            gown[mt][r] = 0.0f;
+        }
+    __syncthreads();
+    for (int s = a.T - 1; s >= 0; s--) {
+        const int it = a.T - 1 - s;
+        const bool cut = s + 1 < a.T && a.seg_len > 0 && (s + 1) % a.seg_len == 0;
+        if (wave == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    if (row >= B) continue;
+                    const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
+                    const int u = u0 + l15;
+                    float dh = a.dout[ro * H + u];
+                    if (!cut) dh += dhz[mt][r] + gown[mt][r];
+                    const float *g = a.gates + ro * 4 * H + u;
+                    const float rg = g[0], zg = g[H], ng = g[2 * H], ghn = g[3 * H];
+                    const float hp = s == 0 ? a.h0[(long)row * H + u] : a.out[pseq_row(row, s - 1, a.Tseg, a.ldN, a.ldB) * H + u];
+                    const float dn = dh * (1.0f - zg), dz = dh * (hp - ng);
+                    const float da = dn * (1.0f - ng * ng);
+                    const float dzp = dz * zg * (1.0f - zg);
+                    const float drp = da * ghn * rg * (1.0f - rg);
+                    if (s > 0) {
+                        pgu64 *gp = (pgu64 *)a.gx + ((long)(s & 1) * B + row) * K3 + u;
+                        const unsigned long long ep = (unsigned long long)(unsigned)(it + 1) << 32;
+                        __hip_atomic_store(gp, ep | __builtin_bit_cast(unsigned, drp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(gp + H, ep | __builtin_bit_cast(unsigned, dzp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(gp + 2 * H, ep | __builtin_bit_cast(unsigned, da * rg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    float *gi = a.dgi + ro * K3 + u, *gh = a.dgh + ro * K3 + u;
+                    gi[0] = drp; gi[H] = dzp; gi[2 * H] = da;
+                    gh[0] = drp; gh[H] = dzp; gh[2 * H] = da * rg;
+                    dhz[mt][r] = dh * zg;
+                }
+        }
+        if (s == 0) break;  // uniform
+        pf32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            acc[mt] = pf32x4{0, 0, 0, 0};
+            const int arow = min(mt * 16 + l15, B - 1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float av[KJ];
+                pseq_gather<KJ>(rs, (((s & 1) * B + arow) * K3 + c * H + kbase) * 8, (unsigned)(it + 1), av, a.sync, &s_fail);
+#pragma unroll
+                for (int j = 0; j < KJ; j++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[c][j], acc[mt], 0, 0, 0);
+            }
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[wave][mt][r][lane] = acc[mt][r];
+        }
+        __syncthreads();
+        if (s_fail) break;
+        if (wave == 0) {
+            const int nw = blockDim.x >> 6;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float p = acc[mt][r];
+                    for (int wv = 1; wv < nw; wv++) p += red[wv][mt][r][lane];
+                    gown[mt][r] = p;
+                }
+        }
+        __syncthreads();  // `red` is rewritten in the next step: wave 0 must be done reading it
     }
 }
 

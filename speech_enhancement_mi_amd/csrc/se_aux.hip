@@ -22,8 +22,8 @@ void launch_k_stft(dim3 grid, size_t lds, hipStream_t st, const StftArgs &a) { h
 
 void launch_k_istft(dim3 grid, size_t lds, hipStream_t st, const IstftArgs &a) { hipLaunchKernelGGL(k_istft, grid, dim3(256), lds, st, a); }
 
-void launch_k_overlap_avg(dim3 grid, hipStream_t st, const float *yseg, float *out, int Nseg, int K, long L, long skip) {
-    hipLaunchKernelGGL(k_overlap_avg, grid, dim3(256), 0, st, yseg, out, Nseg, K, L, skip);
+void launch_k_overlap_avg(dim3 grid, hipStream_t st, const float *yseg, float *out, int Nseg, int K, long L, long skip, const long *Lrow) {
+    hipLaunchKernelGGL(k_overlap_avg, grid, dim3(256), 0, st, yseg, out, Nseg, K, L, skip, Lrow);
 }
 
 void launch_k_final_mask_ew(dim3 grid, hipStream_t st, const MaskEwArgs &a) { hipLaunchKernelGGL(k_final_mask_ew, grid, dim3(256), 0, st, a); }

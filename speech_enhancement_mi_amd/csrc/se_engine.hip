@@ -134,6 +134,8 @@ struct se_engine {
     DevBuf enc_g[SE_MAX_LEVELS];           // CRN_ELU: gated encoder output before the norm
     DevBuf pin[3][2], pre_g, pre_stats[3];  // CRN_ELU preconv chain (inputs ping-ponged: they carry 4 history columns)
     DevBuf yseg;
+    DevBuf ragged_len;       // se_realtime_process_ragged: per-stream lengths (int64) on the device
+    bool ragged_on = false;
     // second-generation convolution path (conv_p.hip.h): activations as split-bf16 planes; SE_PATH=0 selects the first generation
     struct se_convp_state *cp = nullptr;
     int path = 1;
@@ -147,6 +149,7 @@ struct se_engine {
     int skinny_rows = 800;    // SE_GEMM_SKINNY_ROWS: bottleneck GEMMs with up to this many rows run on the skinny fp32 kernel
     int skip_min_batch = 96;  // SE_SKIP_MIN_BATCH: the streaming skip kernel needs at least this many streams
     int gemm_p_env = 1;
+    int gemm_band = 0;        // SE_GEMM_BAND: 0 (default) = banded tile->XCD map where no equal 8-block split exists, 1 = always banded, -1 = never
     DevBuf gruinP[kRing], seqP[4][kRing];  // [PL][B*T][D'] / [PL][B*T][H] bf16 planes
     DevBuf wih_xp;                          // W_ih0 planes with K in the engine's feature order (k_gemm_p)
     int dbg_skip = 0;         // SE_DBG_SKIP bit mask, TIMING EXPERIMENTS ONLY (results are wrong): 1 = no GRU step launches, 2 = no bottleneck
@@ -747,9 +750,17 @@ int launch_gemm_p(se_engine *e, const float *Ap, const float *Wp, const float *b
         const double bytes = (double)Mr * (8 / cx) + (double)Nc * cx;  // x Kd x bytes per element, common to all candidates
         if (!gx || bytes < best) { gx = cx; gy = 8 / cx; best = bytes; }
     }
+    int nblocks = nrt * nct;
+    if (e->gemm_band >= 0 && (!gx || e->gemm_band == 1) && nrt * nct >= 16) {
+        // no equal 8-block split divides the tile grid (B = 256: 21 x 12 tiles): block id -> XCD is id mod 8, so plain row-major order
+        // hands every row tile of A to all eight L2s.  Banded: XCD x takes the `per` consecutive tiles [x per, (x + 1) per)
+        const int per = (nrt * nct + 7) / 8;
+        gx = -1; gy = per;
+        nblocks = 8 * per;
+    }
     GemmPArgs g{reinterpret_cast<const uint4 *>(Ap), reinterpret_cast<const uint4 *>(Wp), (long)Mr * Kd / 8, (long)Nc * Kd / 8, bias, C, Mr, Nc, Kd, ldc, relu,
                 (unsigned)((size_t)PL * Mr * Kd * 2), (unsigned)((size_t)PL * Nc * Kd * 2), nrt, nct, gx, gy};
-    const dim3 grid(nrt * nct);
+    const dim3 grid(nblocks);
     const size_t lds = (size_t)2 * 1536 * PL * 16;
     if (PL == 1) hipLaunchKernelGGL(k_gemm_p<1>, grid, dim3(512), lds, st, g);
     else if (PL == 2) hipLaunchKernelGGL(k_gemm_p<2>, grid, dim3(512), lds, st, g);
@@ -1069,6 +1080,7 @@ int launch_stft(se_engine *e, const float *src, long strideB, long strideM, int 
     a.K = e->K; a.T = e->T; a.F = e->F[0]; a.hop = e->c.hop;
     a.spec = spec; a.sR = sR; a.sT = sT; a.sF = sF;
     a.window = e->window.p; a.tw = reinterpret_cast<const cf2 *>(e->tw.p); a.plan = e->plan;
+    a.Lrow = e->ragged_on ? reinterpret_cast<const long *>(e->ragged_len.p) : nullptr;
     ProfScope ps(e, "k_stft", "stft", 0, st);
     launch_k_stft(dim3(rows, nseg), stft_lds_bytes(e->K, e->N), st, a);
     HIPCHECK(e, hipGetLastError());
@@ -1191,6 +1203,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
 #endif
     if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
     if (const char *s = getenv("SE_GEMM_P")) e->gemm_p_env = atoi(s);
+    if (const char *s = getenv("SE_GEMM_BAND")) e->gemm_band = atoi(s);
     if (const char *s = getenv("SE_GEMM_SKINNY_ROWS")) e->skinny_rows = atoi(s);
     if (const char *s = getenv("SE_SKIP_MIN_BATCH")) e->skip_min_batch = atoi(s);
     e->cp = new se_convp_state();
@@ -1733,9 +1746,26 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         }
     }
     const long skip = lead;  // CRN.py:587-588
-    launch_k_overlap_avg(dim3((unsigned)((length + 255) / 256), batch), st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, skip);
+    launch_k_overlap_avg(dim3((unsigned)((length + 255) / 256), batch), st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, skip,
+                         e->ragged_on ? reinterpret_cast<const long *>(e->ragged_len.p) : nullptr);
     HIPCHECK(e, hipGetLastError());
     return SE_OK;
+}
+
+int se_realtime_process_ragged(se_engine *e, const float *mixture, int batch, int64_t max_length, const int64_t *lengths_host, int flag, float *out,
+                               void *stream) {
+    if (!e || !lengths_host || batch <= 0) return fail(e, SE_ERR_ARG, "bad argument");
+    for (int b = 0; b < batch; b++)
+        if (lengths_host[b] <= 0 || lengths_host[b] > max_length) return fail(e, SE_ERR_ARG, "length of stream %d (%lld) outside (0, %lld]", b, (long long)lengths_host[b], (long long)max_length);
+    int rc = dev_alloc(e, e->ragged_len, (size_t)batch * 2);
+    if (rc) return rc;
+    static_assert(sizeof(long) == sizeof(int64_t), "per-stream lengths are passed to the kernels as long");
+    HIPCHECK(e, hipMemcpyAsync(e->ragged_len.p, lengths_host, (size_t)batch * sizeof(int64_t), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    HIPCHECK(e, hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // the host array is borrowed for the call only
+    e->ragged_on = true;
+    rc = se_realtime_process(e, mixture, batch, max_length, flag, out, stream);
+    e->ragged_on = false;
+    return rc;
 }
 
 static int copy_out(se_engine *e, const float *dev, size_t n, float *host, int64_t cap, int64_t *count, hipStream_t st) {

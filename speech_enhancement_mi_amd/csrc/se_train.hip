@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include <cmath>
@@ -34,6 +35,13 @@ static int pseq_kj(int H) {  // smallest register block that keeps the K split w
     for (int kj : {4, 8, 16, 32})
         if (H % (4 * kj) == 0 && H / (4 * kj) <= 8) return kj;
     return 0;
+}
+
+bool pseq_granules() {  // SE_TRAIN_GRU_EXCHANGE=granule selects the {tag, value} granule exchange (A/B: forward -8 %, backward 3.8x SLOWER - its
+                        // 3H-wide vector makes every wave poll 24 loads per pass); default: arrival counter + publish-first ordering
+    static int mode = -1;
+    if (mode < 0) { const char *v = getenv("SE_TRAIN_GRU_EXCHANGE"); mode = (v && std::string(v) == "granule") ? 1 : 0; }
+    return mode == 1;
 }
 
 void launch_arrange_w(const float *w, float *out, long sCo, long sCi, int Co, int Ci, int ntap, int CC, int nchunk, int CoPad, int one_by_one,
@@ -84,9 +92,14 @@ int se_train_gru_pseq_fwd(const float *gi, const float *h0, const float *whh, co
     if (!gi || !h0 || !whh || !bhh || !out || !hT || !scratch || T <= 0 || Tseg <= 0) return train_fail(SE_ERR_ARG, "null / bad argument");
     if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d (1..32), H = %d unsupported", B, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");  // arrivals + timeout word
     const int kj = se::pseq_kj(H), MT = B > 16 ? 2 : 1;
     se::GruPseqFwdArgs a{gi, h0, whh, bhh, out, gates, hT, scratch + 16, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, (long)ldN, (long)ldB};
+    if (se::pseq_granules()) {  // {tag, value} granules: the whole exchange buffer is zeroed (epochs start at 1)
+        if (hipMemsetAsync(scratch, 0, 64 + (size_t)2 * B * H * 8, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
+        SE_PSEQ_LAUNCH(k_gru_gseq_fwd, a);
+        return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU forward launch failed");
+    }
+    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");  // arrivals + timeout word
     SE_PSEQ_LAUNCH(k_gru_pseq_fwd, a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU forward launch failed");
 }
@@ -97,9 +110,14 @@ int se_train_gru_pseq_bwd(const float *dout, const float *dhT, const float *gate
     if (!dout || !gates || !out || !h0 || !whh_t || !dgi || !dgh || !scratch || T <= 0 || Tseg <= 0) return train_fail(SE_ERR_ARG, "null / bad argument");
     if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d (1..32), H = %d unsupported", B, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
     const int kj = se::pseq_kj(H), MT = B > 16 ? 2 : 1;
     se::GruPseqBwdArgs a{dout, dhT, gates, out, h0, whh_t, dgi, dgh, scratch + 16, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, seg_len, (long)ldN, (long)ldB};
+    if (se::pseq_granules()) {
+        if (hipMemsetAsync(scratch, 0, 64 + (size_t)2 * B * 3 * H * 8, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
+        SE_PSEQ_LAUNCH(k_gru_gseq_bwd, a);
+        return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU backward launch failed");
+    }
+    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
     SE_PSEQ_LAUNCH(k_gru_pseq_bwd, a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU backward launch failed");
 }
@@ -207,7 +225,7 @@ int se_train_gln_fwd(const float *x, int64_t xS, int64_t xC, int64_t xT, float *
     se::TGlnArgs a{};
     a.x = x; a.xS = xS; a.xC = xC; a.xT = xT; a.y = y; a.yS = yS; a.yC = yC; a.yT = yT; a.w = w; a.b = b; a.stats = stats;
     a.C = C; a.T = T; a.Fi = Fi; a.Fo = Fo; a.mode = mode; a.act = act; a.eps_mode = eps_mode;
-    hipLaunchKernelGGL(se::k_tgln_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se::k_tgln_fwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
@@ -219,8 +237,8 @@ int se_train_gln_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const 
     a.dy = dy; a.dS = dS; a.dC = dC; a.dT = dT; a.x = x; a.xS = xS; a.xC = xC; a.xT = xT; a.y = dx; a.w = w;
     a.stats = const_cast<float *>(stats); a.dw_part = dw_part; a.db_part = db_part; a.dpre_part = dpre_part;
     a.C = C; a.T = T; a.Fi = Fi; a.Fo = Fi; a.mode = mode; a.act = act; a.eps_mode = eps_mode;
-    if (mode) hipLaunchKernelGGL(se::k_tgln_bwd_d, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(se::k_tgln_bwd_c, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (mode) hipLaunchKernelGGL(se::k_tgln_bwd_d, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(se::k_tgln_bwd_c, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
@@ -252,7 +270,7 @@ int se_train_skip_fwd(const float *uv, const float *z, const float *nw, const fl
     if (!uv || !z || !nw || !nb || !out || !stats || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
     se::TSkipArgs a{};
     a.uv = uv; a.z = z; a.nw = nw; a.nb = nb; a.out = out; a.stats = stats; a.Co = Co; a.T = T; a.F = F; a.act = act; a.eps_mode = eps_mode;
-    hipLaunchKernelGGL(se::k_tskip_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se::k_tskip_fwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
@@ -262,7 +280,7 @@ int se_train_skip_bwd(const float *dout, const float *uv, const float *z, const 
     se::TSkipArgs a{};
     a.dout = dout; a.uv = uv; a.z = z; a.nw = nw; a.nb = nb; a.stats = const_cast<float *>(stats); a.duv = duv; a.dz = dz;
     a.dnw_part = dnw_part; a.dnb_part = dnb_part; a.dbias_part = dbias_part; a.Co = Co; a.T = T; a.F = F; a.act = act; a.eps_mode = eps_mode;
-    hipLaunchKernelGGL(se::k_tskip_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se::k_tskip_bwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
@@ -271,7 +289,7 @@ int se_train_gate_fwd(const float *tg, const float *w, const float *b, float *y,
     if (!tg || !w || !b || !y || !stats || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
     se::TGateArgs a{};
     a.tg = tg; a.w = w; a.b = b; a.y = y; a.stats = stats; a.C = C; a.T = T; a.F = F; a.eps_mode = eps_mode; a.yS = yS; a.yC = yC; a.yT = yT;
-    hipLaunchKernelGGL(se::k_tgate_fwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se::k_tgate_fwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
@@ -281,13 +299,13 @@ int se_train_gate_bwd(const float *dy, int64_t dS, int64_t dC, int64_t dT, const
     se::TGateArgs a{};
     a.dy = dy; a.tg = tg; a.w = w; a.stats = const_cast<float *>(stats); a.dtg = dtg; a.dw_part = dw_part; a.db_part = db_part; a.dbias_part = dbias_part;
     a.C = C; a.T = T; a.F = F; a.eps_mode = eps_mode; a.yS = dS; a.yC = dC; a.yT = dT;
-    hipLaunchKernelGGL(se::k_tgate_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se::k_tgate_bwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 
 int se_train_elu_bwd(float *da, const float *act, float *dpre_part, int S, int C, int T, int F, void *stream) {
     if (!da || !act || !dpre_part || S <= 0) return train_fail(SE_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(se::k_telu_bwd, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), da, act, dpre_part, C, T * F);
+    hipLaunchKernelGGL(se::k_telu_bwd, dim3(S), dim3(se::kTT), 0, static_cast<hipStream_t>(stream), da, act, dpre_part, C, T * F);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "launch failed");
 }
 

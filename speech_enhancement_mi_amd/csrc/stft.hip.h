@@ -54,6 +54,7 @@ struct StftArgs {
     const cf2 *tw;          // [N] exp(-2 pi i m / N)
     FftPlan plan;
     long seg_off, seg_spec;  // blockIdx.y = segment of a batch of segments: off += y*seg_off, spec += y*seg_spec
+    const long *Lrow;        // optional per-stream lengths [rows / M] (ragged batches): samples beyond a stream's own length read as zeros
 };
 
 // LDS: sig[K+N] | win[N] | tw[N] (cf2) | bufA[kFftBatch*N/2] | bufB[kFftBatch*N/2]
@@ -74,9 +75,10 @@ __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
     const float *src = a.src + (long)(row / a.M) * a.strideB + (long)(row % a.M) * a.strideM;
     const long seg_first = a.off + (long)blockIdx.y * a.seg_off;
     cf2 *spec_out = a.spec + (long)blockIdx.y * a.seg_spec;
+    const long Lr = a.Lrow ? min(a.Lrow[row / a.M], a.L) : a.L;
     for (int i = tid; i < K + N; i += nth) {
         const long k = (long)i - pad + seg_first;
-        sig[i] = (i >= pad && i < pad + K && k >= 0 && k < a.L) ? src[k] : 0.0f;
+        sig[i] = (i >= pad && i < pad + K && k >= 0 && k < Lr) ? src[k] : 0.0f;
     }
     for (int i = tid; i < N; i += nth) { win[i] = a.window[i]; tw[i] = a.tw[i]; }
     __syncthreads();
@@ -165,10 +167,11 @@ __global__ __launch_bounds__(256) void k_istft(IstftArgs a) {
 
 // utility.over_add on the engine's segment outputs (utility.py:373-403) + the K/2 strip of
 // realtime_process (CRN.py:587-588).  yseg [B, Nseg, K] -> out [B, L].
-__global__ void k_overlap_avg(const float *yseg, float *out, int Nseg, int K, long L, long skip) {
+__global__ void k_overlap_avg(const float *yseg, float *out, int Nseg, int K, long L, long skip, const long *Lrow) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= L) return;
+    if (Lrow && i >= Lrow[b]) { out[(long)b * L + i] = 0.0f; return; }  // ragged batch: nothing beyond the stream's own length
     const long P = K / 2;
     const long i2 = i + skip, i1 = i2 + P;
     const float *y = yseg + (long)b * Nseg * K;
@@ -182,7 +185,7 @@ __global__ void k_overlap_avg(const float *yseg, float *out, int Nseg, int K, lo
 // host-side launchers, defined in se_aux.hip
 void launch_k_stft(dim3 grid, size_t lds, hipStream_t st, const StftArgs &a);
 void launch_k_istft(dim3 grid, size_t lds, hipStream_t st, const IstftArgs &a);
-void launch_k_overlap_avg(dim3 grid, hipStream_t st, const float *yseg, float *out, int Nseg, int K, long L, long skip);
+void launch_k_overlap_avg(dim3 grid, hipStream_t st, const float *yseg, float *out, int Nseg, int K, long L, long skip, const long *Lrow = nullptr);
 void aux_set_fft_lds(int stft_bytes, int istft_bytes);
 
 }  // namespace se

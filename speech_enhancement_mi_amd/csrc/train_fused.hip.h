@@ -22,16 +22,23 @@ constexpr float kTEps = 1e-8f;  // CRN.py:11
 __device__ __forceinline__ float t_act(float v, int act) { return act == 1 ? fmaxf(v, 0.0f) : (act == 2 ? (v > 0.0f ? v : expf(v) - 1.0f) : v); }
 __device__ __forceinline__ float t_dact(float v, int act) { return act == 1 ? (v > 0.0f ? 1.0f : 0.0f) : (act == 2 ? (v > 0.0f ? 1.0f : expf(v)) : 1.0f); }
 
-// block-wide sums of up to two values over 256 threads (4 waves), combined in double; every thread gets the result
-__device__ __forceinline__ void t_block_sum2(double &a, double &b, double *red /*[8]*/) {
+// The per-stream kernels run kTW waves per workgroup: a stream has up to 45 k elements and is walked in 2-3 dependent passes, so the
+// pass length (elements / threads) is the launch time; 16 waves instead of 4: k_tgln_fwd 194 -> 107 us, k_tgln_bwd 218 -> 82 us per launch
+// (272 streams, measured in bench.py --mode train).
+constexpr int kTW = 16, kTT = kTW * 64;
+
+// block-wide sums of up to two values over kTT threads, combined in double in a fixed order; every thread gets the result
+__device__ __forceinline__ void t_block_sum2(double &a, double &b, double *red /*[2 * kTW]*/) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) { red[wave * 2] = a; red[wave * 2 + 1] = b; }
     __syncthreads();
-    a = (red[0] + red[2]) + (red[4] + red[6]);
-    b = (red[1] + red[3]) + (red[5] + red[7]);
+    double sa = 0, sb = 0;
+#pragma unroll
+    for (int w = 0; w < kTW; w++) { sa += red[2 * w]; sb += red[2 * w + 1]; }
+    a = sa; b = sb;
 }
 
 __device__ __forceinline__ float t_wave_sum(float v) {
@@ -55,13 +62,13 @@ struct TGlnArgs {
 };
 
 // forward: y = gLN(act(x)); one workgroup per stream, three passes (mean, variance, write)
-__global__ __launch_bounds__(256) void k_tgln_fwd(TGlnArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tgln_fwd(TGlnArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int TF = a.T * a.Fi, n = a.C * TF;
     const float *x = a.x + (long)s * a.xS;
     double sum = 0, dummy = 0;
-    for (int e = tid; e < n; e += 256) {
+    for (int e = tid; e < n; e += kTT) {
         const int c = e / TF, r = e - c * TF, t = r / a.Fi, f = r - t * a.Fi;
         sum += (double)t_act(x[c * a.xC + t * a.xT + f], a.act);
     }
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void k_tgln_fwd(TGlnArgs a) {
     const float mean = (float)(sum / n);
     double sq = 0;
     dummy = 0;
-    for (int e = tid; e < n; e += 256) {
+    for (int e = tid; e < n; e += kTT) {
         const int c = e / TF, r = e - c * TF, t = r / a.Fi, f = r - t * a.Fi;
         const float d = t_act(x[c * a.xC + t * a.xT + f], a.act) - mean;
         sq += (double)(d * d);
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void k_tgln_fwd(TGlnArgs a) {
     if (tid == 0) { a.stats[2 * s] = mean; a.stats[2 * s + 1] = inv; }
     float *y = a.y + (long)s * a.yS;
     const int TFo = a.T * a.Fo, no = a.C * TFo;
-    for (int e = tid; e < no; e += 256) {
+    for (int e = tid; e < no; e += kTT) {
         const int c = e / TFo, r = e - c * TFo, t = r / a.Fo, f = r - t * a.Fo;
         float v = 0.0f;
         if (f < a.Fi) {
@@ -92,15 +99,15 @@ __global__ __launch_bounds__(256) void k_tgln_fwd(TGlnArgs a) {
 }
 
 // backward, mode 0 (per-channel affine): wave w owns channels c = w, w + 4, ... so the per-channel sums need no atomics
-__global__ __launch_bounds__(256) void k_tgln_bwd_c(TGlnArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tgln_bwd_c(TGlnArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TF = a.T * a.Fi, n = a.C * TF;
     const float *x = a.x + (long)s * a.xS;
     const float *dy = a.dy + (long)s * a.dS;
     const float mean = a.stats[2 * s], inv = a.stats[2 * s + 1];
     double S1 = 0, S2 = 0;
-    for (int c = wave; c < a.C; c += 4) {
+    for (int c = wave; c < a.C; c += kTW) {
         const float wc = a.w[c];
         float pw = 0.0f, pb = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_tgln_bwd_c(TGlnArgs a) {
     const float sd = 1.0f / inv - kTEps;
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n) / (a.eps_mode ? fmaxf(sd, 1e-30f) : sd);
     float *dx = a.y + (long)s * a.xS;
-    for (int c = wave; c < a.C; c += 4) {
+    for (int c = wave; c < a.C; c += kTW) {
         const float wc = a.w[c];
         float pp = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -138,15 +145,15 @@ __global__ __launch_bounds__(256) void k_tgln_bwd_c(TGlnArgs a) {
 }
 
 // backward, mode 1 (per-feature affine, d = c * Fi + f; the norm after fc_output_layer): thread owns features d = tid, tid + 256, ...
-__global__ __launch_bounds__(256) void k_tgln_bwd_d(TGlnArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tgln_bwd_d(TGlnArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int D = a.C * a.Fi, n = D * a.T;
     const float *x = a.x + (long)s * a.xS;
     const float *dy = a.dy + (long)s * a.dS;
     const float mean = a.stats[2 * s], inv = a.stats[2 * s + 1];
     double S1 = 0, S2 = 0;
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += kTT) {
         const int c = d / a.Fi, f = d - c * a.Fi;
         const float wd = a.w[d];
         float pw = 0.0f, pb = 0.0f;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void k_tgln_bwd_d(TGlnArgs a) {
     const float sd = 1.0f / inv - kTEps;
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n) / (a.eps_mode ? fmaxf(sd, 1e-30f) : sd);
     float *dx = a.y + (long)s * a.xS;
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += kTT) {
         const int c = d / a.Fi, f = d - c * a.Fi;
         const float wd = a.w[d];
         float pp = 0.0f;
@@ -221,25 +228,25 @@ struct TSkipArgs {
     int Co, T, F, act, eps_mode;
 };
 
-__global__ __launch_bounds__(256) void k_tskip_fwd(TSkipArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tskip_fwd(TSkipArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int TF = a.T * a.F, n = a.Co * TF;
     const float *u = a.uv + (long)s * 2 * n, *v = u + n;
     double sum = 0, dummy = 0;
-    for (int e = tid; e < n; e += 256) sum += (double)v[e];
+    for (int e = tid; e < n; e += kTT) sum += (double)v[e];
     t_block_sum2(sum, dummy, red);
     const float mean = (float)(sum / n);
     double sq = 0;
     dummy = 0;
-    for (int e = tid; e < n; e += 256) { const float d = v[e] - mean; sq += (double)(d * d); }
+    for (int e = tid; e < n; e += kTT) { const float d = v[e] - mean; sq += (double)(d * d); }
     t_block_sum2(sq, dummy, red);
     const float var = (float)(sq / n);
     const float inv = 1.0f / ((a.eps_mode ? sqrtf(var) : sqrtf(var + kTEps)) + kTEps);
     if (tid == 0) { a.stats[2 * s] = mean; a.stats[2 * s + 1] = inv; }
     const float *z = a.z + (long)s * n;
     float *o = a.out + (long)s * n;
-    for (int e = tid; e < n; e += 256) {
+    for (int e = tid; e < n; e += kTT) {
         const int c = e / TF;
         const float vn = (v[e] - mean) * inv * a.nw[c] + a.nb[c];
         const float m = 1.0f / (1.0f + expf(-vn));
@@ -247,8 +254,8 @@ __global__ __launch_bounds__(256) void k_tskip_fwd(TSkipArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_tskip_bwd(TSkipArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tskip_bwd(TSkipArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TF = a.T * a.F, n = a.Co * TF;
     const float *u = a.uv + (long)s * 2 * n, *v = u + n;
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void k_tskip_bwd(TSkipArgs a) {
     float *du = a.duv + (long)s * 2 * n, *dv = du + n, *dz = a.dz + (long)s * n;
     const float mean = a.stats[2 * s], inv = a.stats[2 * s + 1];
     double S1 = 0, S2 = 0;
-    for (int c = wave; c < a.Co; c += 4) {
+    for (int c = wave; c < a.Co; c += kTW) {
         const float wc = a.nw[c], bc = a.nb[c];
         float pw = 0.0f, pb = 0.0f, pu = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void k_tskip_bwd(TSkipArgs a) {
     t_block_sum2(S1, S2, red);
     const float sd = 1.0f / inv - kTEps;
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n) / (a.eps_mode ? fmaxf(sd, 1e-30f) : sd);
-    for (int c = wave; c < a.Co; c += 4) {
+    for (int c = wave; c < a.Co; c += kTW) {
         const float wc = a.nw[c], bc = a.nb[c];
         float pp = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -381,31 +388,31 @@ struct TGateArgs {
     long yS, yC, yT;  // element (s, c, t, f) of y (forward) / dy (backward) at s * yS + c * yC + t * yT + f
 };
 
-__global__ __launch_bounds__(256) void k_tgate_fwd(TGateArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tgate_fwd(TGateArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int TF = a.T * a.F, n = a.C * TF;
     const float *t = a.tg + (long)s * 2 * n, *g = t + n;
     double sum = 0, dummy = 0;
-    for (int e = tid; e < n; e += 256) sum += (double)(t[e] / (1.0f + expf(-g[e])));
+    for (int e = tid; e < n; e += kTT) sum += (double)(t[e] / (1.0f + expf(-g[e])));
     t_block_sum2(sum, dummy, red);
     const float mean = (float)(sum / n);
     double sq = 0;
     dummy = 0;
-    for (int e = tid; e < n; e += 256) { const float d = t[e] / (1.0f + expf(-g[e])) - mean; sq += (double)(d * d); }
+    for (int e = tid; e < n; e += kTT) { const float d = t[e] / (1.0f + expf(-g[e])) - mean; sq += (double)(d * d); }
     t_block_sum2(sq, dummy, red);
     const float var = (float)(sq / n);
     const float inv = 1.0f / ((a.eps_mode ? sqrtf(var) : sqrtf(var + kTEps)) + kTEps);
     if (tid == 0) { a.stats[2 * s] = mean; a.stats[2 * s + 1] = inv; }
     float *y = a.y + (long)s * a.yS;
-    for (int e = tid; e < n; e += 256) {
+    for (int e = tid; e < n; e += kTT) {
         const int c = e / TF, r = e - c * TF, tt = r / a.F, f = r - tt * a.F;
         y[c * a.yC + tt * a.yT + f] = (t[e] / (1.0f + expf(-g[e])) - mean) * inv * a.w[c] + a.b[c];
     }
 }
 
-__global__ __launch_bounds__(256) void k_tgate_bwd(TGateArgs a) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(kTT) void k_tgate_bwd(TGateArgs a) {
+    __shared__ double red[2 * kTW];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TF = a.T * a.F, n = a.C * TF;
     const float *t = a.tg + (long)s * 2 * n, *g = t + n;
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256) void k_tgate_bwd(TGateArgs a) {
     float *dt = a.dtg + (long)s * 2 * n, *dg = dt + n;
     const float mean = a.stats[2 * s], inv = a.stats[2 * s + 1];
     double S1 = 0, S2 = 0;
-    for (int c = wave; c < a.C; c += 4) {
+    for (int c = wave; c < a.C; c += kTW) {
         const float wc = a.w[c];
         float pw = 0.0f, pb = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void k_tgate_bwd(TGateArgs a) {
     t_block_sum2(S1, S2, red);
     const float sd = 1.0f / inv - kTEps;
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n) / (a.eps_mode ? fmaxf(sd, 1e-30f) : sd);
-    for (int c = wave; c < a.C; c += 4) {
+    for (int c = wave; c < a.C; c += kTW) {
         const float wc = a.w[c];
         float pt = 0.0f, pg = 0.0f;
         for (int r = lane; r < TF; r += 64) {
@@ -450,9 +457,9 @@ __global__ __launch_bounds__(256) void k_tgate_bwd(TGateArgs a) {
 
 // da -> dy through a = ELU(y), from the saved activation only: ELU'(y) = 1 (a > 0) or e^y = a + 1; also the per-channel sums of dy
 // (the producing convolution's bias gradient) as [S][C] slabs
-__global__ __launch_bounds__(256) void k_telu_bwd(float *da, const float *aact, float *dpre_part, int C, int TF) {
+__global__ __launch_bounds__(kTT) void k_telu_bwd(float *da, const float *aact, float *dpre_part, int C, int TF) {
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += kTW) {
         float pp = 0.0f;
         for (int r = lane; r < TF; r += 64) {
             const long e = ((long)s * C + c) * TF + r;

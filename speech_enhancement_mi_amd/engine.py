@@ -18,7 +18,7 @@ SE_MAX_LEVELS = 8
 
 EXPORTS = [
     "se_abi_version", "se_config_size", "fsn_config_size", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_reset_stream", "se_step",
-    "se_realtime_process", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
+    "se_realtime_process", "se_realtime_process_ragged", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
@@ -78,6 +78,7 @@ def load_library():
     L.se_reset_stream.argtypes = [vp, C.c_int, vp]
     L.se_step.argtypes = [vp, fp, fp, vp]
     L.se_realtime_process.argtypes = [vp, fp, C.c_int, C.c_int64, C.c_int, fp, vp]
+    L.se_realtime_process_ragged.argtypes = [vp, fp, C.c_int, C.c_int64, i64p, C.c_int, fp, vp]
     L.se_stft.argtypes = [vp, fp, C.c_int, fp, vp]
     L.se_istft.argtypes = [vp, fp, C.c_int, fp, vp]
     L.se_forward.argtypes = [vp, fp, fp, vp]
@@ -238,13 +239,22 @@ class Engine:
         self._check(self.lib.se_step(self._h, self._dev(wav_in, (B, self.M, self.K)), self._dev(wav_out, (B, self.K)), self._stream()))
         return wav_out
 
-    def realtime_process(self, mixture, flag=False, out=None):
+    def realtime_process(self, mixture, flag=False, out=None, lengths=None):
+        """lengths (optional, [B] ints <= L): ragged batch - every stream is processed as if alone with its own length."""
         import torch
         B, M, L = mixture.shape
         if M != self.M:
             raise RuntimeError(f"expected {self.M} microphones, got {M}")
         if out is None:
             out = torch.empty((B, L), dtype=torch.float32, device=mixture.device)
+        if lengths is not None:
+            ln = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+            if len(ln) != B:
+                raise RuntimeError(f"{len(ln)} lengths for a batch of {B}")
+            arr = (C.c_int64 * B)(*ln)
+            self._check(self.lib.se_realtime_process_ragged(self._h, self._dev(mixture), B, L, arr, int(bool(flag)), self._dev(out, (B, L)), self._stream()))
+            self.batch = B
+            return out
         self._check(self.lib.se_realtime_process(self._h, self._dev(mixture), B, L, int(bool(flag)), self._dev(out, (B, L)), self._stream()))
         self.batch = B
         return out

@@ -232,7 +232,7 @@ def _scratch(dev, B, H):
     key = (dev.index, B, H)
     t = _pseq_scratch.get(key)
     if t is None:
-        t = _pseq_scratch[key] = torch.zeros(16 + 6 * B * H, device=dev, dtype=torch.float32)
+        t = _pseq_scratch[key] = torch.zeros(16 + 12 * B * H, device=dev, dtype=torch.float32)  # [2][B][3H] 8-byte granules
     return t
 
 

@@ -560,3 +560,21 @@ def test_fused_crn_elu_train_step_vs_float64_autograd(cfgname, utts, seconds):
     e_t, e_h = _rel(r32[2], r64[2]), _rel(rh[2], r64[2])
     print(f"CRN_ELU flat-gradient error vs float64 autograd: torch fp32 {e_t:.2e}, training kernels {e_h:.2e}")
     assert e_h < max(3.0 * e_t, 1e-4), (e_h, e_t)
+
+
+def test_ragged_batch_equals_each_stream_alone():
+    """se_realtime_process_ragged: utterances of 1 .. 3.75 s in one zero-padded batch (data_c.py:155-173) - every stream gets the output it
+    would get alone (its own utility.padding zeros), and zeros beyond its length."""
+    e, e1 = _engine(FULL400, seed=4), _engine(FULL400, seed=4)
+    lens = [16000, 41234, 60000, 23999, 1, 3200]
+    Lmax = max(lens)
+    mix, _ = synth.synth_utterances(len(lens), Lmax, 3, seed=33)
+    for b, l in enumerate(lens):
+        mix[b, :, l:] = 7.0          # garbage beyond the stream's length must not be read
+    y = e.realtime_process(_cuda(mix), lengths=lens).cpu().numpy()
+    for b, l in enumerate(lens):
+        alone = e1.realtime_process(_cuda(mix[b:b + 1, :, :l])).cpu().numpy()
+        assert rel_rms(y[b, :l], alone[0]) < 2e-6 or l == 1, (b, l)
+        assert np.all(y[b, l:] == 0.0)
+    with pytest.raises(RuntimeError, match="outside"):
+        e.realtime_process(_cuda(mix), lengths=[Lmax + 1] * len(lens))
