@@ -143,12 +143,46 @@ __global__ __launch_bounds__(256) void k_corr_wgrad(WgradArgs a) {
         bool s_ok = n_ok;
         if (ts < 0) { ts += a.T; sbase = a.Sprev; s_ok = s_ok && a.Sprev != nullptr && ts >= 0; }
         const float *sp = sbase ? sbase + (((long)bb * a.Cb + bch) * a.T + max(ts, 0)) * a.Fs : a.S;
-        for (int m = 0; m < a.Fm; m += 2) {
-            const int mm = m + kh;
-            const float av = (a_ok && mm < a.Fm) ? gp[mm] : 0.0f;
-            const int f = a.fs * mm + kf - 2;
-            const float bv = (s_ok && mm < a.Fm && f >= 0 && f < a.Fs) ? sp[f] : 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        // Positions are contracted in blocks of 8: MFMA j of a block pairs positions {m0 + j, m0 + 4 + j} (the order of the contraction
+        // is free), so lane half kh owns the four CONSECUTIVE positions m0 + 4 kh + [0, 4): one 16-byte load of G per block instead of four
+        // scalar ones (each wave instruction gathers from 32 different rows: the instruction count was the bound, 13 TFLOP/s), and
+        // the matching S window f0 + fs * [0, 4) as one or two 16-byte loads.  Windows that touch a row end take guarded scalar loads.
+        struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };  // rows have odd lengths: dword-aligned 16-byte loads
+        auto load_blk = [&](int m0, float (&av)[4], float (&bv)[4]) {
+            const int mb = m0 + 4 * kh;
+            const int f0 = a.fs * mb + kf - 2;
+            if (a_ok && mb + 4 <= a.Fm) {
+                const f4u q = *reinterpret_cast<const f4u *>(gp + mb);
+                av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) av[j] = (a_ok && mb + j < a.Fm) ? gp[mb + j] : 0.0f;
+            }
+            if (s_ok && f0 >= 0 && f0 + 3 * a.fs < a.Fs && (a.fs == 1 || f0 + 8 <= a.Fs)) {
+                const f4u q0 = *reinterpret_cast<const f4u *>(sp + f0);
+                if (a.fs == 1) { bv[0] = q0.x; bv[1] = q0.y; bv[2] = q0.z; bv[3] = q0.w; }
+                else {
+                    const f4u q1 = *reinterpret_cast<const f4u *>(sp + f0 + 4);
+                    asm volatile("" ::"v"(q0.y), "v"(q0.w), "v"(q1.y), "v"(q1.w));  // keep the unused lanes "used": hipcc otherwise narrows the two
+                                                                                     // 16-byte loads to four scalar ones (the instruction count is the bound)
+                    bv[0] = q0.x; bv[1] = q0.z; bv[2] = q1.x; bv[3] = q1.z;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int f = f0 + a.fs * j;
+                    bv[j] = (s_ok && f >= 0 && f < a.Fs) ? sp[f] : 0.0f;
+                }
+            }
+        };
+        float av[4], bv[4], an[4], bn[4];
+        load_blk(0, an, bn);
+        for (int m0 = 0; m0 < a.Fm; m0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { av[j] = an[j]; bv[j] = bn[j]; }
+            if (m0 + 8 < a.Fm) load_blk(m0 + 8, an, bn);  // one block ahead of the MFMAs
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
         }
     }
     // D layout: column (n) on the lane, rows (a) = (r & 3) + 8 (r >> 2) + 4 kh in the 16 registers
