@@ -215,13 +215,16 @@ int se_train_gru_seq_fwd(const float *gi, const float *h0, const float *whh, con
 int se_train_gru_seq_bwd(const float *dout, const float *dhT, const float *gates, const float *out, const float *h0, const float *whh_t, float *dgi,
                          float *dgh, float *scratch, int B, int T, int H, int seg_len, void *stream);
 
-/* ONE persistent launch per GRU layer and direction (csrc/gru_pseq.hip.h): H/16 resident workgroups keep their W_hh slice in
- * registers and exchange the state vector per step through write-through stores + an agent-scope arrival counter.
- * Replaces T dependent step launches (round 2) for micro-batches of up to 32 streams.  Rows of gi / out / gates / dout / dgi /
- * dgh are addressed as row(b, s) = (s / Tseg) * ldN + b * ldB + s % Tseg, which covers [B][T] (Tseg = T, ldN = 0, ldB = T) and
- * the training forward's segment-major [N][B][Tseg] (ldN = B * Tseg, ldB = Tseg).  scratch: 16 + 4 * B * H floats (forward),
- * 16 + 12 * B * H floats (backward) - the state vector travels as 8-byte {step tag, value} granules; word [1] of scratch is non-zero after a bounded-spin timeout (results invalid).
- * gates may be NULL in the forward (inference / no_grad).  seg_len as in se_train_gru_seq_bwd. */
+/* ONE persistent launch per GRU layer and direction (csrc/gru_pseq.hip.h): H/16 resident workgroups per group of <= 32 streams keep
+ * their W_hh slice in registers and exchange the state vector per step through write-through stores + an agent-scope arrival counter.
+ * Replaces T dependent step launches (round 2).  Any number of streams: more than 32 run as independent 16-stream groups of the same
+ * launch (rows must then be [B][T], ldN = 0) - which is how the training backward runs, because the state is detached at every segment
+ * seam (CRN.py:281): S = segments x utterances independent streams of Tseg steps.  Rows of gi / out / gates / dout / dgi / dgh are
+ * addressed as row(b, s) = (s / Tseg) * ldN + b * ldB + s % Tseg, which covers [B][T] (Tseg = T, ldN = 0, ldB = T) and the training
+ * forward's segment-major [N][B][Tseg] (ldN = B * Tseg, ldB = Tseg).  scratch: se_train_gru_pseq_scratch_floats(B, H) floats; word [1]
+ * of scratch is non-zero after a bounded-spin timeout (results invalid).  gates may be NULL in the forward (inference / no_grad).
+ * seg_len as in se_train_gru_seq_bwd. */
+int se_train_gru_pseq_scratch_floats(int B, int H);
 int se_train_gru_pseq_supported(int B, int H);
 int se_train_gru_pseq_fwd(const float *gi, const float *h0, const float *whh, const float *bhh, float *out, float *gates, float *hT,
                           float *scratch, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, void *stream);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
     for (int i = 0; i < NT; i++) {
         const int pc = min(p0 + (cg + i * NCG) * 32 + l31, p1 - 1);
         const int t = (int)(((float)pc + 0.5f) * invFP), m = pc - t * a.FP;
-        lane_base[i] = ((t - ta) * St + a.s * m) * 16;  // byte offset inside plane 0
+        lane_base[i] = ((t - ta) * St + (a.deint ? m : a.s * m)) * 16;  // byte offset inside plane 0
     }
     int toffL[NPAIR];  // per lane half: LDS offset of entry 2*step + half = (tap, octet), tap-major
 #pragma unroll
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
                     const int q = (int)(((float)it + 0.5f) * invNpos);  // LDS slot = (pl * CO + oc) * Npos + pe
                     const int pe = it - q * Npos;
                     const int pl = q / CO, oc = q - pl * CO;
-                    const int r = (int)(((float)pe + 0.5f) * invSt), col = pe - r * St;
+                    const int r = (int)(((float)pe + 0.5f) * invSt), slot = pe - r * St;
+                    const int col = a.deint ? (slot < a.Sh ? 2 * slot : 2 * (slot - a.Sh) + 1) : slot;  // even columns first, then the odd ones
                     const int g = NGp > 1 ? (int)(((float)r + 0.5f) * invRTp) : 0, j = r - g * RTp;
                     const int ts = ta + a.tlo_off + g * a.dil + j;
                     const int fi = col - a.colpad;

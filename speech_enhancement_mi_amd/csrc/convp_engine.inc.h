@@ -113,7 +113,13 @@ int plan_conv_p(se_engine *e, ConvPPlan &pl, int Ci, int Co, int FP, int Fi, int
     ConvPArgs &a = pl.a;
     a.C8 = C8; a.Ci = Ci; a.Co = Co; a.CoPad = CoPad; a.T = T; a.Fi = Fi; a.FP = FP;
     a.s = s; a.colpad = colpad; a.tlo_off = tlo_off; a.ngroup = ngroup; a.dil = dil; a.ntap = ntap;
-    for (int t = 0; t < ntap; t++) { a.rowgrp[t] = taps[t][2]; a.coloff[t] = taps[t][3]; }
+    a.deint = (s == 2 && e->convp_deint) ? 1 : 0;
+    a.Sh = (St + 1) / 2;
+    for (int t = 0; t < ntap; t++) {
+        a.rowgrp[t] = taps[t][2];
+        const int c = taps[t][3];
+        a.coloff[t] = a.deint ? (c & 1) * a.Sh + (c >> 1) : c;
+    }
     a.nchunk = nchunk; a.St = St; a.act = act; a.relu_lo = relu_lo; a.relu_hi = relu_hi;
     a.out_mode = out_mode; a.row_perm = out_mode == kPOutP || out_mode == kPOutBlend || out_mode == kPOutGate;
     a.valid_m = FP; a.par_rows = 0; a.stats = nullptr;

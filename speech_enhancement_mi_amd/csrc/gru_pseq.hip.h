@@ -36,9 +36,10 @@ struct GruPseqFwdArgs {
     float *gates;       // rows of 4H: r, z, n, gh_n (saved for the backward sweep); may be null (no_grad forward)
     float *hT;          // [B][H]
     float *hx;          // [2][B][H] exchange buffer (sc1 traffic only)
-    unsigned *sync;     // [0] arrivals, [1] timeout flag; zeroed by the host before every launch
-    int B, T, H, Tseg;  // row(b, s) = (s / Tseg) * ldN + b * ldB + s % Tseg
+    unsigned *sync;     // per group g (blockIdx.y) 16 words: [16 g] arrivals; word [1] = timeout flag of the launch; zeroed by the host
+    int B, T, H, Tseg;  // row(b, s) = (s / Tseg) * ldN + b * ldB + s % Tseg;  B = streams of the WHOLE launch
     long ldN, ldB;
+    int Bg;             // streams per group: blockIdx.y = g handles streams [g Bg, min(B, (g + 1) Bg)) with its own counter and exchange slab
 };
 
 struct GruPseqBwdArgs {
@@ -53,6 +54,7 @@ struct GruPseqBwdArgs {
     unsigned *sync;
     int B, T, H, Tseg, seg_len;  // seg_len > 0: the carried state is detached every seg_len steps (CRN.py:281)
     long ldN, ldB;
+    int Bg;              // streams per group (see GruPseqFwdArgs)
 };
 
 __device__ __forceinline__ long pseq_row(int b, int s, int Tseg, long ldN, long ldB) {
@@ -62,16 +64,16 @@ __device__ __forceinline__ long pseq_row(int b, int s, int Tseg, long ldN, long 
 
 // one lane: arrive / wait until `target` arrivals are visible (bounded; returns false on timeout)
 __device__ __forceinline__ void pseq_arrive(unsigned *sync) { __hip_atomic_fetch_add((pgu32 *)sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool pseq_wait(unsigned *sync, unsigned target) {
-    pgu32 *cnt = (pgu32 *)sync;
+__device__ __forceinline__ bool pseq_wait(unsigned *sync, unsigned *tmo_word, unsigned target) {
+    pgu32 *cnt = (pgu32 *)sync, *tmo = (pgu32 *)tmo_word;
     const long long t0 = wall_clock64();
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0) {
-            if (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;  // somebody else gave up
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;  // somebody else gave up
             if (wall_clock64() - t0 > kPseqSpinLimit) {
-                __hip_atomic_store(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
@@ -85,10 +87,16 @@ __global__ __launch_bounds__(512) void k_gru_pseq_fwd(GruPseqFwdArgs a) {
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int H = a.H, B = a.B, u0 = blockIdx.x * 16;
+    const int grp = blockIdx.y, b0 = grp * a.Bg;
+    const int H = a.H, B = min(a.Bg, a.B - b0), u0 = blockIdx.x * 16;
     const unsigned NWG = gridDim.x;
     const int kbase = wave * 4 * KJ + kq * KJ;
     if (tid == 0) s_fail = 0;
+    unsigned *const tmo = a.sync + 1;
+    a.sync += 16 * grp;                               // this group's arrival counter
+    a.hx += (long)grp * 2 * a.Bg * H;                 // ... and exchange slab
+    a.gi += (long)b0 * a.ldB * 3 * H; a.out += (long)b0 * a.ldB * H; a.h0 += (long)b0 * H; a.hT += (long)b0 * H;
+    if (a.gates) a.gates += (long)b0 * a.ldB * 4 * H;
     // this lane's share of the W_hh slice: gate g, unit u0 + l15, k = kbase .. kbase + KJ
     float w[3][KJ];
 #pragma unroll
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(512) void k_gru_pseq_fwd(GruPseqFwdArgs a) {
                     }
                     if (s + 1 == a.T) a.hT[(long)row * H + u0 + l15] = hown[mt][r];
                 }
-            if (s + 1 < a.T && lane == 0 && !pseq_wait(a.sync, NWG * (unsigned)(s + 1))) s_fail = 1;
+            if (s + 1 < a.T && lane == 0 && !pseq_wait(a.sync, tmo, NWG * (unsigned)(s + 1))) s_fail = 1;
         }
         __syncthreads();
         if (s_fail) break;  // uniform
@@ -231,10 +239,17 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int H = a.H, B = a.B, u0 = blockIdx.x * 16, K3 = 3 * H;
+    const int grp = blockIdx.y, b0 = grp * a.Bg;
+    const int H = a.H, B = min(a.Bg, a.B - b0), u0 = blockIdx.x * 16, K3 = 3 * H;
     const unsigned NWG = gridDim.x;
     const int kbase = wave * 4 * KJ + kq * KJ;
     if (tid == 0) s_fail = 0;
+    unsigned *const tmo = a.sync + 1;
+    a.sync += 16 * grp;
+    a.gx += (long)grp * 2 * a.Bg * K3;
+    a.dout += (long)b0 * a.ldB * H; a.gates += (long)b0 * a.ldB * 4 * H; a.out += (long)b0 * a.ldB * H; a.h0 += (long)b0 * H;
+    a.dgi += (long)b0 * a.ldB * K3; a.dgh += (long)b0 * a.ldB * K3;
+    if (a.dhT) a.dhT += (long)b0 * H;
     // W_hh^T slice: unit (column of W_hh) u0 + l15, contraction index jj = c * H + kbase + j
     float w[3][KJ];
 #pragma unroll
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
                     gi[0] = vo[mt][r][0]; gi[H] = vo[mt][r][1]; gi[2 * H] = vo[mt][r][2];
                     gh[0] = vo[mt][r][0]; gh[H] = vo[mt][r][1]; gh[2 * H] = vo[mt][r][3];
                 }
-            if (s > 0 && lane == 0 && !pseq_wait(a.sync, NWG * (unsigned)(it + 1))) s_fail = 1;
+            if (s > 0 && lane == 0 && !pseq_wait(a.sync, tmo, NWG * (unsigned)(it + 1))) s_fail = 1;
         }
         if (s == 0) break;  // uniform
         __syncthreads();
@@ -375,262 +390,8 @@ __global__ __launch_bounds__(512) void k_gru_pseq_bwd(GruPseqBwdArgs a) {
 }
 
 
-// ---- granule exchange (cdna_hip_programming.md Guideline 16, R2: "the data IS the flag") ------------------------------------------------
-// The counter form above pays, per step: the producer's store drain (s_waitcnt vmcnt(0) behind write-through stores), an atomic arrival,
-// a poll round trip, and only then the consumers' loads - 7.2 / 8.2 us per forward / backward step.  Here every exchanged value travels as
-// ONE aligned 8-byte granule {tag = step epoch, value} written by one sc1 store; a consumer wave simply re-reads the granules it needs
-// (16-byte sc1 loads = two granules) until every tag shows the epoch it waits for: no drain, no counter, no separate poll.
-// Ping-pong safety: a producer can write epoch e + 2 into a buffer only after every workgroup has produced epoch e + 1, which each does
-// after its waves consumed epoch e from that buffer.  The exchange buffer is zeroed by the host before every launch (epochs start at 1).
-typedef __attribute__((address_space(1))) unsigned long long pgu64;
-
-template <int KJ>
-__device__ __forceinline__ bool pseq_gather(const __amdgpu_buffer_rsrc_t rs, int off_bytes, unsigned epoch, float (&av)[KJ], unsigned *sync, int *s_fail) {
-    // granules are handled as 64-bit words {tag : value}: (hipcc 7.2 folded `q[2]` of a 4 x u32 view of the 16-byte load into `q[0]` at the
-    // loop exit - every odd granule came back as its even neighbour; the u64 form below compiles to what it says)
-    typedef unsigned long long pu64x2 __attribute__((ext_vector_type(2)));
-    const long long t0 = wall_clock64();
-    unsigned spins = 0;
-    pu64x2 q[KJ / 2];
-    bool done = false;
-    for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < KJ / 2; j++) {
-            q[j] = __builtin_bit_cast(pu64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, off_bytes + j * 16, 0, 16));  // sc1: two granules
-            ok = ok && (unsigned)(q[j][0] >> 32) == epoch && (unsigned)(q[j][1] >> 32) == epoch;
-        }
-        if (__all(ok)) { done = true; break; }
-        if ((++spins & 31u) == 0) {
-            if (*s_fail || wall_clock64() - t0 > kPseqSpinLimit) {
-                *s_fail = 1;
-                __hip_atomic_store((pgu32 *)sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < KJ / 2; j++) {
-        av[2 * j] = __builtin_bit_cast(float, (unsigned)(q[j][0] & 0xffffffffULL));
-        av[2 * j + 1] = __builtin_bit_cast(float, (unsigned)(q[j][1] & 0xffffffffULL));
-    }
-    return done;
-}
-
-template <int KJ, int MT>
-__global__ __launch_bounds__(512) void k_gru_gseq_fwd(GruPseqFwdArgs a) {
-    __shared__ float red[8][MT][3][4][64];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int H = a.H, B = a.B, u0 = blockIdx.x * 16;
-    const int kbase = wave * 4 * KJ + kq * KJ;
-    if (tid == 0) s_fail = 0;
-    float w[3][KJ];
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-        const float *wp = a.whh + ((long)g * H + u0 + l15) * H + kbase;
-#pragma unroll
-        for (int j = 0; j < KJ; j += 4) {
-            const float4 q = *reinterpret_cast<const float4 *>(wp + j);
-            w[g][j] = q.x; w[g][j + 1] = q.y; w[g][j + 2] = q.z; w[g][j + 3] = q.w;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (int)(2L * B * H * 8), 0x00020000);  // granules [2][B][H]
-    float hown[MT][4], bh[3];
-    if (wave == 0) {
-#pragma unroll
-        for (int g = 0; g < 3; g++) bh[g] = a.bhh[g * H + u0 + l15];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = mt * 16 + kq * 4 + r;
-                hown[mt][r] = row < B ? a.h0[(long)row * H + u0 + l15] : 0.0f;
-            }
-    }
-    __syncthreads();
-    for (int s = 0; s < a.T; s++) {
-        float gir[MT][4], giz[MT][4], gin[MT][4];
-        if (wave == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = min(mt * 16 + kq * 4 + r, B - 1);
-                    const float *g = a.gi + pseq_row(row, s, a.Tseg, a.ldN, a.ldB) * 3 * H + u0 + l15;
-                    gir[mt][r] = g[0]; giz[mt][r] = g[H]; gin[mt][r] = g[2 * H];
-                }
-        }
-        pf32x4 acc[MT][3];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int g = 0; g < 3; g++) acc[mt][g] = pf32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const int arow = min(mt * 16 + l15, B - 1);
-            float av[KJ];
-            if (s == 0) {
-                const float *hp = a.h0 + (long)arow * H + kbase;
-#pragma unroll
-                for (int j = 0; j < KJ; j += 4) {
-                    const float4 q = *reinterpret_cast<const float4 *>(hp + j);
-                    av[j] = q.x; av[j + 1] = q.y; av[j + 2] = q.z; av[j + 3] = q.w;
-                }
-            } else {
-                pseq_gather<KJ>(rs, ((((s - 1) & 1) * B + arow) * H + kbase) * 8, (unsigned)s, av, a.sync, &s_fail);
-            }
-#pragma unroll
-            for (int j = 0; j < KJ; j++) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[0][j], acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[1][j], acc[mt][1], 0, 0, 0);
-                acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[2][j], acc[mt][2], 0, 0, 0);
-            }
-        }
-        if (wave > 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int g = 0; g < 3; g++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) red[wave][mt][g][r][lane] = acc[mt][g][r];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const int nw = blockDim.x >> 6;
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = mt * 16 + kq * 4 + r;
-                    float p0 = acc[mt][0][r], p1 = acc[mt][1][r], p2 = acc[mt][2][r];
-                    for (int wv = 1; wv < nw; wv++) { p0 += red[wv][mt][0][r][lane]; p1 += red[wv][mt][1][r][lane]; p2 += red[wv][mt][2][r][lane]; }
-                    if (row < B) {
-                        const float gh_n = p2 + bh[2];
-                        const float rg = 1.0f / (1.0f + expf(-(gir[mt][r] + p0 + bh[0])));
-                        const float zg = 1.0f / (1.0f + expf(-(giz[mt][r] + p1 + bh[1])));
-                        const float ng = tanhf(gin[mt][r] + rg * gh_n);
-                        const float hn = (1.0f - zg) * ng + zg * hown[mt][r];
-                        hown[mt][r] = hn;
-                        if (s + 1 < a.T) {  // publish first: the other workgroups wait for exactly these granules
-                            pgu64 *gp = (pgu64 *)a.hx + ((long)(s & 1) * B + row) * H + u0 + l15;
-                            __hip_atomic_store(gp, ((unsigned long long)(unsigned)(s + 1) << 32) | __builtin_bit_cast(unsigned, hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else a.hT[(long)row * H + u0 + l15] = hn;
-                        const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
-                        a.out[ro * H + u0 + l15] = hn;
-                        if (a.gates) {
-                            float *gs = a.gates + ro * 4 * H + u0 + l15;
-                            gs[0] = rg; gs[H] = zg; gs[2 * H] = ng; gs[3 * H] = gh_n;
-                        }
-                    }
-                }
-        }
-        __syncthreads();
-        if (s_fail) break;  // uniform
-    }
-}
-
-template <int KJ, int MT>
-__global__ __launch_bounds__(512) void k_gru_gseq_bwd(GruPseqBwdArgs a) {
-    __shared__ float red[8][MT][4][64];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int H = a.H, B = a.B, u0 = blockIdx.x * 16, K3 = 3 * H;
-    const int kbase = wave * 4 * KJ + kq * KJ;
-    if (tid == 0) s_fail = 0;
-    float w[3][KJ];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float *wp = a.whh_t + (long)(u0 + l15) * K3 + c * H + kbase;
-#pragma unroll
-        for (int j = 0; j < KJ; j += 4) {
-            const float4 q = *reinterpret_cast<const float4 *>(wp + j);
-            w[c][j] = q.x; w[c][j + 1] = q.y; w[c][j + 2] = q.z; w[c][j + 3] = q.w;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.gx, 0, (int)(2L * B * K3 * 8), 0x00020000);  // granules [2][B][3H]
-    float dhz[MT][4], gown[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = mt * 16 + kq * 4 + r;
-            dhz[mt][r] = (wave == 0 && a.dhT && row < B) ? a.dhT[(long)row * H + u0 + l15] : 0.0f;
-            gown[mt][r] = 0.0f;
-        }
-    __syncthreads();
-    for (int s = a.T - 1; s >= 0; s--) {
-        const int it = a.T - 1 - s;
-        const bool cut = s + 1 < a.T && a.seg_len > 0 && (s + 1) % a.seg_len == 0;
-        if (wave == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = mt * 16 + kq * 4 + r;
-                    if (row >= B) continue;
-                    const long ro = pseq_row(row, s, a.Tseg, a.ldN, a.ldB);
-                    const int u = u0 + l15;
-                    float dh = a.dout[ro * H + u];
-                    if (!cut) dh += dhz[mt][r] + gown[mt][r];
-                    const float *g = a.gates + ro * 4 * H + u;
-                    const float rg = g[0], zg = g[H], ng = g[2 * H], ghn = g[3 * H];
-                    const float hp = s == 0 ? a.h0[(long)row * H + u] : a.out[pseq_row(row, s - 1, a.Tseg, a.ldN, a.ldB) * H + u];
-                    const float dn = dh * (1.0f - zg), dz = dh * (hp - ng);
-                    const float da = dn * (1.0f - ng * ng);
-                    const float dzp = dz * zg * (1.0f - zg);
-                    const float drp = da * ghn * rg * (1.0f - rg);
-                    if (s > 0) {
-                        pgu64 *gp = (pgu64 *)a.gx + ((long)(s & 1) * B + row) * K3 + u;
-                        const unsigned long long ep = (unsigned long long)(unsigned)(it + 1) << 32;
-                        __hip_atomic_store(gp, ep | __builtin_bit_cast(unsigned, drp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(gp + H, ep | __builtin_bit_cast(unsigned, dzp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(gp + 2 * H, ep | __builtin_bit_cast(unsigned, da * rg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    float *gi = a.dgi + ro * K3 + u, *gh = a.dgh + ro * K3 + u;
-                    gi[0] = drp; gi[H] = dzp; gi[2 * H] = da;
-                    gh[0] = drp; gh[H] = dzp; gh[2 * H] = da * rg;
-                    dhz[mt][r] = dh * zg;
-                }
-        }
-        if (s == 0) break;  // uniform
-        pf32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            acc[mt] = pf32x4{0, 0, 0, 0};
-            const int arow = min(mt * 16 + l15, B - 1);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float av[KJ];
-                pseq_gather<KJ>(rs, (((s & 1) * B + arow) * K3 + c * H + kbase) * 8, (unsigned)(it + 1), av, a.sync, &s_fail);
-#pragma unroll
-                for (int j = 0; j < KJ; j++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[c][j], acc[mt], 0, 0, 0);
-            }
-        }
-        if (wave > 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) red[wave][mt][r][lane] = acc[mt][r];
-        }
-        __syncthreads();
-        if (s_fail) break;
-        if (wave == 0) {
-            const int nw = blockDim.x >> 6;
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float p = acc[mt][r];
-                    for (int wv = 1; wv < nw; wv++) p += red[wv][mt][r][lane];
-                    gown[mt][r] = p;
-                }
-        }
-        __syncthreads();  // `red` is rewritten in the next step: wave 0 must be done reading it
-    }
-}
+// (A {tag, value} granule exchange - Guideline 16 R2, "the data IS the flag" - was built and measured in round 3: forward -8 %, backward
+//  3.8x SLOWER (its 3H-wide vector makes every wave poll 24 loads per pass), and hipcc 7.2 folded `q[2]` of a 4 x u32 view of the 16-byte
+//  granule load into `q[0]` at the poll loop's exit.  It was removed; DESIGN.md 6 keeps the numbers.)
 
 }  // namespace se

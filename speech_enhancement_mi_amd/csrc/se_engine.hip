@@ -149,6 +149,7 @@ struct se_engine {
     int skinny_rows = 800;    // SE_GEMM_SKINNY_ROWS: bottleneck GEMMs with up to this many rows run on the skinny fp32 kernel
     int skip_min_batch = 96;  // SE_SKIP_MIN_BATCH: the streaming skip kernel needs at least this many streams
     int gemm_p_env = 1;
+    int convp_deint = 1;      // SE_CONVP_DEINT=0: stride-2 convolutions keep interleaved LDS patch rows (2-way ds_read_b128 bank conflicts)
     int gemm_band = 0;        // SE_GEMM_BAND: 0 (default) = banded tile->XCD map where no equal 8-block split exists, 1 = always banded, -1 = never
     DevBuf gruinP[kRing], seqP[4][kRing];  // [PL][B*T][D'] / [PL][B*T][H] bf16 planes
     DevBuf wih_xp;                          // W_ih0 planes with K in the engine's feature order (k_gemm_p)
@@ -1204,6 +1205,7 @@ int se_create(const se_config *cfg, int device, se_engine **out) {
     if (const char *s = getenv("SE_GRU_LAG")) e->gru_lag = atoi(s);
     if (const char *s = getenv("SE_GEMM_P")) e->gemm_p_env = atoi(s);
     if (const char *s = getenv("SE_GEMM_BAND")) e->gemm_band = atoi(s);
+    if (const char *s = getenv("SE_CONVP_DEINT")) e->convp_deint = atoi(s);
     if (const char *s = getenv("SE_GEMM_SKINNY_ROWS")) e->skinny_rows = atoi(s);
     if (const char *s = getenv("SE_SKIP_MIN_BATCH")) e->skip_min_batch = atoi(s);
     e->cp = new se_convp_state();

@@ -37,13 +37,6 @@ static int pseq_kj(int H) {  // smallest register block that keeps the K split w
     return 0;
 }
 
-bool pseq_granules() {  // SE_TRAIN_GRU_EXCHANGE=granule selects the {tag, value} granule exchange (A/B: forward -8 %, backward 3.8x SLOWER - its
-                        // 3H-wide vector makes every wave poll 24 loads per pass); default: arrival counter + publish-first ordering
-    static int mode = -1;
-    if (mode < 0) { const char *v = getenv("SE_TRAIN_GRU_EXCHANGE"); mode = (v && std::string(v) == "granule") ? 1 : 0; }
-    return mode == 1;
-}
-
 void launch_arrange_w(const float *w, float *out, long sCo, long sCi, int Co, int Ci, int ntap, int CC, int nchunk, int CoPad, int one_by_one,
                       const int *kf, const int *kt, hipStream_t st) {
     TArrangeArgs a{};
@@ -69,11 +62,14 @@ extern "C" {
 
 const char *se_train_last_error(void) { return se::g_train_error.c_str(); }
 
-int se_train_gru_pseq_supported(int B, int H) { return B >= 1 && B <= 32 && H > 0 && H % 16 == 0 && se::pseq_kj(H) != 0; }
+int se_train_gru_pseq_supported(int B, int H) { return B >= 1 && H > 0 && H % 16 == 0 && se::pseq_kj(H) != 0; }
 
+// One launch for ANY number of independent streams: groups of Bg <= 32 streams (blockIdx.y), each group = H/16 resident workgroups with
+// their own arrival counter and exchange slab.  Blocks are dispatched group-major, so a group's workgroups become resident together and a
+// group that does not fit yet simply waits in the dispatcher until an earlier group drains - groups never wait on each other.
 #define SE_PSEQ_LAUNCH(KERNEL, ARGS)                                                                         \
     do {                                                                                                     \
-        const dim3 grid(H / 16), block(64 * (H / (4 * kj)));                                                 \
+        const dim3 grid(H / 16, groups), block(64 * (H / (4 * kj)));                                         \
         if (MT == 1) {                                                                                       \
             if (kj == 4) hipLaunchKernelGGL((se::KERNEL<4, 1>), grid, block, 0, st, ARGS);                   \
             else if (kj == 8) hipLaunchKernelGGL((se::KERNEL<8, 1>), grid, block, 0, st, ARGS);              \
@@ -87,19 +83,31 @@ int se_train_gru_pseq_supported(int B, int H) { return B >= 1 && B <= 32 && H > 
         }                                                                                                    \
     } while (0)
 
+static void pseq_groups(int B, int &Bg, int &groups, int &MT) {
+    // 16-stream groups (one MFMA row tile) once there are more streams than two groups' worth: more groups in flight, shorter steps
+    Bg = B <= 32 ? B : 16;
+    if (B <= 32 && B > 16) Bg = B;
+    groups = (B + Bg - 1) / Bg;
+    MT = Bg > 16 ? 2 : 1;
+}
+
+int se_train_gru_pseq_scratch_floats(int B, int H) {
+    int Bg, groups, MT;
+    pseq_groups(B, Bg, groups, MT);
+    return 16 * groups + groups * 2 * Bg * 3 * H;
+}
+
 int se_train_gru_pseq_fwd(const float *gi, const float *h0, const float *whh, const float *bhh, float *out, float *gates, float *hT,
                           float *scratch, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, void *stream) {
     if (!gi || !h0 || !whh || !bhh || !out || !hT || !scratch || T <= 0 || Tseg <= 0) return train_fail(SE_ERR_ARG, "null / bad argument");
-    if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d (1..32), H = %d unsupported", B, H);
+    if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d, H = %d unsupported", B, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int kj = se::pseq_kj(H), MT = B > 16 ? 2 : 1;
-    se::GruPseqFwdArgs a{gi, h0, whh, bhh, out, gates, hT, scratch + 16, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, (long)ldN, (long)ldB};
-    if (se::pseq_granules()) {  // {tag, value} granules: the whole exchange buffer is zeroed (epochs start at 1)
-        if (hipMemsetAsync(scratch, 0, 64 + (size_t)2 * B * H * 8, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
-        SE_PSEQ_LAUNCH(k_gru_gseq_fwd, a);
-        return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU forward launch failed");
-    }
-    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");  // arrivals + timeout word
+    int Bg, groups, MT;
+    pseq_groups(B, Bg, groups, MT);
+    if (groups > 1 && ldN != 0) return train_fail(SE_ERR_ARG, "more than 32 streams need rows [B][T] (ldN = 0)");
+    const int kj = se::pseq_kj(H);
+    if (hipMemsetAsync(scratch, 0, (size_t)64 * groups, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");  // arrival counters + timeout word
+    se::GruPseqFwdArgs a{gi, h0, whh, bhh, out, gates, hT, scratch + 16 * groups, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, (long)ldN, (long)ldB, Bg};
     SE_PSEQ_LAUNCH(k_gru_pseq_fwd, a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU forward launch failed");
 }
@@ -108,16 +116,14 @@ int se_train_gru_pseq_bwd(const float *dout, const float *dhT, const float *gate
                           float *dgi, float *dgh, float *scratch, int B, int T, int H, int Tseg, int64_t ldN, int64_t ldB, int seg_len,
                           void *stream) {
     if (!dout || !gates || !out || !h0 || !whh_t || !dgi || !dgh || !scratch || T <= 0 || Tseg <= 0) return train_fail(SE_ERR_ARG, "null / bad argument");
-    if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d (1..32), H = %d unsupported", B, H);
+    if (!se_train_gru_pseq_supported(B, H)) return train_fail(SE_ERR_ARG, "persistent GRU: B = %d, H = %d unsupported", B, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int kj = se::pseq_kj(H), MT = B > 16 ? 2 : 1;
-    se::GruPseqBwdArgs a{dout, dhT, gates, out, h0, whh_t, dgi, dgh, scratch + 16, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, seg_len, (long)ldN, (long)ldB};
-    if (se::pseq_granules()) {
-        if (hipMemsetAsync(scratch, 0, 64 + (size_t)2 * B * 3 * H * 8, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
-        SE_PSEQ_LAUNCH(k_gru_gseq_bwd, a);
-        return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU backward launch failed");
-    }
-    if (hipMemsetAsync(scratch, 0, 64, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
+    int Bg, groups, MT;
+    pseq_groups(B, Bg, groups, MT);
+    if (groups > 1 && ldN != 0) return train_fail(SE_ERR_ARG, "more than 32 streams need rows [B][T] (ldN = 0)");
+    const int kj = se::pseq_kj(H);
+    if (hipMemsetAsync(scratch, 0, (size_t)64 * groups, st) != hipSuccess) return train_fail(SE_ERR_HIP, "memset failed");
+    se::GruPseqBwdArgs a{dout, dhT, gates, out, h0, whh_t, dgi, dgh, scratch + 16 * groups, reinterpret_cast<unsigned *>(scratch), B, T, H, Tseg, seg_len, (long)ldN, (long)ldB, Bg};
     SE_PSEQ_LAUNCH(k_gru_pseq_bwd, a);
     return hipGetLastError() == hipSuccess ? SE_OK : train_fail(SE_ERR_HIP, "persistent GRU backward launch failed");
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
     "se_train_last_error", "se_train_conv_layout_query", "se_train_conv", "se_train_conv_wgrad", "se_train_gemm", "se_train_gemm_tn", "se_train_gru_step",
-    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd",
+    "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_scratch_floats", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd",
     "se_sig_create", "se_sig_destroy", "se_sig_stft", "se_sig_istft", "se_train_ola_fwd", "se_train_ola_bwd", "se_train_feat", "se_train_mask_fwd",
     "se_train_mask_bwd", "se_train_gln_fwd", "se_train_gln_bwd", "se_train_colsum", "se_train_colsum_tall", "se_train_skip_fwd", "se_train_skip_bwd",
     "se_train_add", "se_train_add3", "se_train_gate_fwd", "se_train_gate_bwd", "se_train_elu_bwd", "se_train_pre5", "se_train_gru_hprev", "se_train_conv_ws_floats", "se_train_conv_w", "se_train_conv_wgrad_det", "se_train_gemm_tn_det", "se_synth_last_error", "se_synth_rir", "se_synth_rir_tail", "se_synth_fir", "se_synth_mix",
@@ -114,6 +114,7 @@ def load_library():
     L.se_train_gru_seq_fwd.argtypes = [vp] * 8 + [i32, i32, i32, vp]
     L.se_train_gru_seq_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, vp]
     L.se_train_gru_pseq_supported.argtypes = [i32, i32]
+    L.se_train_gru_pseq_scratch_floats.argtypes = [i32, i32]
     L.se_train_gru_pseq_fwd.argtypes = [vp] * 8 + [i32, i32, i32, i32, i64, i64, vp]
     L.se_train_gru_pseq_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, i64, i64, i32, vp]
     L.se_sig_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]

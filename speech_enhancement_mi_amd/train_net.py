@@ -22,6 +22,15 @@ from . import engine as _engine
 from . import train_ops as K
 
 _sig_cache = {}
+_side_streams = {}
+PIPELINE_LAYERS = True   # training forward: GRU layers as a wavefront over segments on one HIP stream per layer (False: layer after layer)
+
+
+def _side_stream(dev, idx):
+    key = (dev.index, idx)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 
 
 def _sig(dev, n_fft, win, hop, seg):
@@ -234,18 +243,53 @@ class CRNFunction(torch.autograd.Function):
         g = model.gru.sequence_model
         H, NL = g.hidden_size, g.num_layers
         R = S * T
-        layer_in, outs, gates, h0s, hTs = seq, [], [], [], []
+        outs, gates, h0s, hTs = [], [], [], []
+        gi0 = K._gemm(seq, g.weight_ih_l0, g.bias_ih_l0)
         for l in range(NL):
-            w_ih, w_hh = getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}")
-            b_ih, b_hh = getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}")
-            gi = K._gemm(layer_in, w_ih, b_ih)
-            h0 = state["h"][l] if state is not None and state["h"] is not None else torch.zeros(B, H, device=dev)
-            out = _new(R, H, dev=dev)
-            gt = _new(R, 4 * H, dev=dev)
-            hT = _new(B, H, dev=dev)
-            K._gru_seq_fwd(gi, h0, w_hh, b_hh, out, gt, hT, B, N * T, H, T, B * T, T)
-            outs.append(out); gates.append(gt); h0s.append(h0); hTs.append(hT)
-            layer_in = out
+            h0s.append(state["h"][l] if state is not None and state["h"] is not None else torch.zeros(B, H, device=dev))
+            outs.append(_new(R, H, dev=dev)); gates.append(_new(R, 4 * H, dev=dev))
+        if NL == 1 or N < 4 or not PIPELINE_LAYERS:
+            layer_in = seq
+            for l in range(NL):
+                gi = gi0 if l == 0 else K._gemm(layer_in, getattr(g, f"weight_ih_l{l}"), getattr(g, f"bias_ih_l{l}"))
+                hT = _new(B, H, dev=dev)
+                K._gru_seq_fwd(gi, h0s[l], getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"), outs[l], gates[l], hT, B, N * T, H, T, B * T, T)
+                hTs.append(hT)
+                layer_in = outs[l]
+        else:
+            # Layer wavefront over segments: the recurrence is sequential in time, but layer l of segment n only needs layer l - 1 of the
+            # SAME segment.  Every layer gets its own HIP stream and walks the utterance one segment (T steps, one persistent launch)
+            # at a time; layer l's segment n waits for an event of layer l - 1's segment n, so the layers run one segment apart:
+            # (N + NL - 1) x T dependent steps instead of NL x N x T.
+            cur = torch.cuda.current_stream()
+            streams = [cur] + [_side_stream(dev, l) for l in range(1, NL)]
+            hall = [_new(N, B, H, dev=dev) for _ in range(NL)]            # the state after every segment (the next segment's h0)
+            gis = [gi0] + [_new(R, 3 * H, dev=dev) for _ in range(1, NL)]
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            for l in range(1, NL):
+                streams[l].wait_event(fork)
+            done = [[None] * N for _ in range(NL)]
+            rows = B * T
+            for n in range(N):
+                for l in range(NL):
+                    with torch.cuda.stream(streams[l]):
+                        if l > 0:
+                            streams[l].wait_event(done[l - 1][n])
+                            _run("k_gemm_skinny", 2.0 * rows * 3 * H * H, lib.se_train_gemm, _p(outs[l - 1], n * rows * H), _p(getattr(g, f"weight_ih_l{l}")),
+                                 _p(getattr(g, f"bias_ih_l{l}")), _p(gis[l], n * rows * 3 * H), rows, 3 * H, H, 0, K._st())
+                        sc = K._scratch(dev, B, H, tag=l)
+                        h_in = h0s[l] if n == 0 else hall[l][n - 1]
+                        _run("k_gru_pseq_fwd", 2.0 * B * 3 * H * H * T, lib.se_train_gru_pseq_fwd, _p(gis[l], n * rows * 3 * H), _p(h_in),
+                             _p(getattr(g, f"weight_hh_l{l}")), _p(getattr(g, f"bias_hh_l{l}")), _p(outs[l], n * rows * H), _p(gates[l], n * rows * 4 * H),
+                             _p(hall[l][n]), _p(sc), B, T, H, T, 0, T, K._st())
+                        ev = torch.cuda.Event()
+                        ev.record(streams[l])
+                        done[l][n] = ev
+            for l in range(1, NL):
+                cur.wait_event(done[l][N - 1])
+            hTs = [hall[l][N - 1] for l in range(NL)]
+            layer_in = outs[NL - 1]
         fc = model.gru.fc_output_layer
         o_fc = K._gemm(layer_in, fc.weight, fc.bias)  # [R, D] pre-activation
         xd = _new(S, CL, T, FL, dev=dev)
@@ -364,9 +408,14 @@ class CRNFunction(torch.autograd.Function):
             w_ih, w_hh = getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}")
             out, gt, h0 = sv["outs"][l], sv["gates"][l], sv["h0s"][l]
             dgi, dgh = _new(R, 3 * H, dev=dev), _new(R, 3 * H, dev=dev)
-            K._gru_seq_bwd(dlayer, None, gt, out, h0, transpose(w_hh), dgi, dgh, B, N * T, H, T, B * T, T, T)
             hp = _new(R, H, dev=dev)
             _run("k_gru_hprev", 0.0, lib.se_train_gru_hprev, _p(out), _p(h0), _p(hp), B, N * T, H, T, B * T, T, st())
+            # The carried state is detached at every segment seam (CRN.py:281), so NOTHING flows back across a seam: the N segments of an
+            # utterance are independent in the backward sweep.  In the segment-major layout the rows are already [S = N*B][T]: the
+            # BPTT runs as S streams of T steps (groups of <= 32 streams per persistent launch) instead of B streams of N*T steps -
+            # 21 dependent steps instead of 714.  Each stream's entering state is row 0 of its h_{s-1} block.
+            h0s = hp.view(S, T, H)[:, 0].contiguous()
+            K._gru_seq_bwd(dlayer, None, gt, out, h0s, transpose(w_hh), dgi, dgh, S, T, H, T, 0, T, 0)
             x_l = sv["seq"] if l == 0 else sv["outs"][l - 1]
             grads[f"gru.sequence_model.weight_ih_l{l}"] = gemm_tn(dgi, x_l)
             grads[f"gru.sequence_model.weight_hh_l{l}"] = gemm_tn(dgh, hp)

@@ -227,12 +227,13 @@ class _LinearFn(torch.autograd.Function):
 _pseq_scratch = {}
 
 
-def _scratch(dev, B, H):
-    """Exchange buffer + arrival / timeout words of the persistent GRU launches (stream-ordered reuse)."""
-    key = (dev.index, B, H)
+def _scratch(dev, B, H, tag=0):
+    """Exchange buffer + arrival / timeout words of the persistent GRU launches (stream-ordered reuse; `tag` separates launches that
+    run concurrently on different streams)."""
+    key = (dev.index, B, H, tag)
     t = _pseq_scratch.get(key)
     if t is None:
-        t = _pseq_scratch[key] = torch.zeros(16 + 12 * B * H, device=dev, dtype=torch.float32)  # [2][B][3H] 8-byte granules
+        t = _pseq_scratch[key] = torch.zeros(_lib().se_train_gru_pseq_scratch_floats(B, H), device=dev, dtype=torch.float32)
     return t
 
 
@@ -248,15 +249,10 @@ def pseq_check():
 def _gru_seq_fwd(gi, h0, w_hh, b_hh, out, gates, hT, B, T, H, Tseg, ldN, ldB):
     """All T steps of one layer.  gi / out / gates rows are addressed as row(b, s) = (s // Tseg) * ldN + b * ldB + s % Tseg."""
     lib = _lib()
-    if lib.se_train_gru_pseq_supported(min(B, 32), H):
-        for b0 in range(0, B, 32):  # one persistent launch per group of <= 32 streams
-            nb = min(32, B - b0)
-            sc = _scratch(gi.device, nb, H)
-            off = b0 * ldB
-            with _Timed("k_gru_pseq_fwd", 2.0 * nb * 3 * H * H * T):
-                _chk(lib.se_train_gru_pseq_fwd(C.c_void_p(gi.data_ptr() + 4 * off * 3 * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh), _p(b_hh),
-                                               C.c_void_p(out.data_ptr() + 4 * off * H), C.c_void_p(gates.data_ptr() + 4 * off * 4 * H),
-                                               C.c_void_p(hT.data_ptr() + 4 * b0 * H), _p(sc), nb, T, H, Tseg, ldN, ldB, _st()))
+    if lib.se_train_gru_pseq_supported(B, H) and (B <= 32 or ldN == 0):  # ONE persistent launch (groups of <= 32 streams inside it)
+        sc = _scratch(gi.device, B, H)
+        with _Timed("k_gru_pseq_fwd", 2.0 * B * 3 * H * H * T):
+            _chk(lib.se_train_gru_pseq_fwd(_p(gi), _p(h0), _p(w_hh), _p(b_hh), _p(out), _p(gates), _p(hT), _p(sc), B, T, H, Tseg, ldN, ldB, _st()))
         return
     if Tseg != T or ldB != T:
         raise RuntimeError(f"hidden size {H}: no persistent GRU kernel, and the step-launch kernels take [B][T] rows only")
@@ -271,17 +267,11 @@ def _gru_seq_fwd(gi, h0, w_hh, b_hh, out, gates, hT, B, T, H, Tseg, ldN, ldB):
 
 def _gru_seq_bwd(dout, dhT, gates, out, h0, w_hh_t, dgi, dgh, B, T, H, Tseg, ldN, ldB, seg_len):
     lib = _lib()
-    if lib.se_train_gru_pseq_supported(min(B, 32), H):
-        for b0 in range(0, B, 32):
-            nb = min(32, B - b0)
-            sc = _scratch(dout.device, nb, H)
-            off = b0 * ldB
-            dh = None if dhT is None else C.c_void_p(dhT.data_ptr() + 4 * b0 * H)
-            with _Timed("k_gru_pseq_bwd", 2.0 * nb * 3 * H * H * T):
-                _chk(lib.se_train_gru_pseq_bwd(C.c_void_p(dout.data_ptr() + 4 * off * H), dh, C.c_void_p(gates.data_ptr() + 4 * off * 4 * H),
-                                               C.c_void_p(out.data_ptr() + 4 * off * H), C.c_void_p(h0.data_ptr() + 4 * b0 * H), _p(w_hh_t),
-                                               C.c_void_p(dgi.data_ptr() + 4 * off * 3 * H), C.c_void_p(dgh.data_ptr() + 4 * off * 3 * H), _p(sc),
-                                               nb, T, H, Tseg, ldN, ldB, seg_len, _st()))
+    if lib.se_train_gru_pseq_supported(B, H) and (B <= 32 or ldN == 0):
+        sc = _scratch(dout.device, B, H)
+        with _Timed("k_gru_pseq_bwd", 2.0 * B * 3 * H * H * T):
+            _chk(lib.se_train_gru_pseq_bwd(_p(dout), _p(dhT), _p(gates), _p(out), _p(h0), _p(w_hh_t), _p(dgi), _p(dgh), _p(sc), B, T, H, Tseg, ldN, ldB,
+                                           seg_len, _st()))
         return
     if Tseg != T or ldB != T:
         raise RuntimeError(f"hidden size {H}: no persistent GRU kernel, and the step-launch kernels take [B][T] rows only")
