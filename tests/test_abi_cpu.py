@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared():
     text = open(os.path.join(ROOT, "include", "se_engine.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:se|fsn)_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:se|fsn)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported():
