@@ -135,7 +135,14 @@ struct LstmStepArgs {
     __bf16 *hout_p;
     long p_plane;      // elements per plane of hprev_p / hout_p (R * H)
     long x_plane, x_ld; // elements per plane and row stride of x_p (layer 0: the unfolded input planes [PL][R][SI]; layers >= 1: R * H, H)
+#ifdef SE_LSTM_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: per-segment cycle sums of one wave (never read by the kernel)
+#endif
 };
+
+#ifdef SE_LSTM_STAMPS
+#define SE_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 // PL = operand planes: 3 = fp32-accurate (six products), 2 = "bf16x3" (hi, mid: three products, fsn_config.precision = 2)
 // PLANES = the A operand ([x_t | h_{t-1}]) arrives pre-split (x_p, hprev_p): staging is a pure copy; false = fp32 operand split in the loop
@@ -184,11 +191,22 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
         }
     };
     issue(0);
+#ifdef SE_LSTM_STAMPS
+    unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, sum[5] = {0, 0, 0, 0, 0};
+#endif
     for (int ck = 0; ck < nck; ck++) {
         const int k0 = ck * kGemmKC;
         const bool from_x = k0 < a.K1p;
         const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
+#ifdef SE_LSTM_STAMPS
+        SE_STAMP(ts0);
+#endif
         __syncthreads();
+#ifdef SE_LSTM_STAMPS
+        SE_STAMP(ts1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SE_STAMP(ts2);
+#endif
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
@@ -216,7 +234,13 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
             const bool ok = h0 + (r & 31) < H;
             *reinterpret_cast<uint4 *>(&Wl[plane][r * kXLd + q]) = ok ? qw[it] : make_uint4(0, 0, 0, 0);
         }
+#ifdef SE_LSTM_STAMPS
+        SE_STAMP(ts3);
+#endif
         __syncthreads();
+#ifdef SE_LSTM_STAMPS
+        SE_STAMP(ts4);
+#endif
         if (ck + 1 < nck) issue(ck + 1);
 #pragma unroll
         for (int ks = 0; ks < kGemmKC; ks += 16) {
@@ -240,7 +264,17 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
                 acc[g] = c;
             }
         }
+#ifdef SE_LSTM_STAMPS
+        SE_STAMP(ts5);  // MFMAs issued (not retired): the tail shows up in the next iteration's barrier segment
+        sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4;
+#endif
     }
+#ifdef SE_LSTM_STAMPS
+    if (a.stamps && blockIdx.x == 5 && blockIdx.y == gridDim.y / 2 && tid == 64) {
+        for (int i = 0; i < 5; i++) a.stamps[i] = sum[i];
+        a.stamps[5] = nck;
+    }
+#endif
     // epilogue: torch.nn.LSTM cell, gate order i, f, g, o
     const int j = h0 + l31;
     if (j >= H) return;
@@ -267,6 +301,196 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
             if (PL > 2) a.hout_p[2 * a.p_plane + idx] = ll;
         }
     }
+}
+
+// ---- the same step on a 256-row x 64-unit (256 gate columns) tile, 8 waves ---------------------------------------------------------
+// In-kernel stamps of k_lstm_step_x6 at the sub-band model's shape (R = B*F = 51 456, H = 384; fp32 mode, per 32-deep chunk and wave):
+// 1 600 cycles staging (split + ds_write), 3 000 cycles for 48 MFMAs (1 536 of matrix-pipe time: the B fragments are read just in
+// time, and the other workgroup's staging shares the SIMD's issue slots), 500 in barriers; the global loads are hidden (100 cycles).
+// (Issuing the loads two chunks ahead from a second register set changes nothing: -2 %.)  Per MFMA the 128 x 128 tile pays too much around it.  Here a workgroup owns 256 rows x 64 units: wave w = rows (w & 3) * 64 .. + 64
+// (two 32-row MFMA tiles) x units (w >> 2) * 32 .. + 32, the four gates of a unit in the same lane (acc[rt][gate]): 96 MFMAs per
+// chunk against the same 16 split values per lane and 18 instead of 30 fragment reads per 48, half the operand re-reads out of L2.
+//   * W never touches registers: each wave issues 2 * PL `buffer_load ... lds` of 1 KB (16 weight rows x 64 B) per chunk into a
+//     double-buffered stage, one chunk ahead (a register-staged W made hipcc sink the loads to the end of the iteration, exposed).
+//   * LDS rows are 64 B (32 bf16) unpadded; 16-B slot s of row r is stored at slot s ^ ((r >> 2) & 3): a ds_read_b128 lane group
+//     (16 rows distinct mod 16, one k slot) covers all 16 slots of the 256-B bank row, conflict-free.  LDS-DMA destinations are
+//     lane-linear, so the swizzle is applied to the lane's SOURCE k offset.
+//   * The fp32 -> split-bf16 conversion of chunk ck + 1 happens in registers between the two MFMA groups of chunk ck; the store phase
+//     between the barriers is 4 * PL ds_write_b64 per lane.
+// LDS: (2 W stages + 1 A stage) * PL * 16 KB = 144 KB (fp32 mode): one workgroup of 8 waves per CU.
+constexpr int kLbM = 256, kLbU = 64, kLbPlane = kLbM * kGemmKC;  // bf16 elements per operand plane (16 KB)
+template <int PL>
+__global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
+    extern __shared__ __align__(16) unsigned char lstm_lds[];
+    __bf16 *Wst = reinterpret_cast<__bf16 *>(lstm_lds);            // [2][PL][256 rows][32]
+    __bf16 *Ap = Wst + 2 * PL * kLbPlane;                           // [PL][256 rows][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 32;
+    const int m0 = blockIdx.y * kLbM, h0 = blockIdx.x * kLbU;
+    const int H = a.H, Hp = (H + 31) & ~31, Kt = a.K1p + Hp;
+    const int nck = Kt / kGemmKC;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rt][g][r] = 0.0f;
+
+    // W by LDS-DMA: instruction j of this wave fills plane j >> 1, rows (wave + 8 (j & 1)) * 16 .. + 16; lane i -> row + (i >> 2), physical slot i & 3
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(a.Wp), 0, (unsigned)((long)PL * 4 * H * Kt * 2), 0x00020000);
+    unsigned woff[2 * PL];
+#pragma unroll
+    for (int j = 0; j < 2 * PL; j++) {
+        const int r = (wave + 8 * (j & 1)) * 16 + (lane >> 2);
+        const int ks = (lane & 3) ^ ((r >> 2) & 3);
+        const int wrow = (r >> 6) * H + h0 + (r & 63);
+        woff[j] = (unsigned)((((long)(j >> 1) * 4 * H + wrow) * Kt + ks * 8) * 2);
+    }
+    auto dma_w = [&](int ck) {
+        __bf16 *dst = Wst + (ck & 1) * PL * kLbPlane;
+#pragma unroll
+        for (int j = 0; j < 2 * PL; j++) {
+            const unsigned v = woff[j];  // a local: with the array element as the argument hipcc's host pass drops the kernel's stub without a diagnostic
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(dst + (j >> 1) * kLbPlane + (wave + 8 * (j & 1)) * 16 * kGemmKC), 16,
+                                                     v, ck * kGemmKC * 2, 0, 0);
+        }
+    };
+    f32x4 qa[4];
+    bf16x4 pa[4][PL];
+    auto issue = [&](int ck) {
+        const int k0 = ck * kGemmKC;
+        const bool from_x = k0 < a.K1p;
+        const float *src = from_x ? a.x : a.hprev;
+        const long ld = from_x ? a.ldx : (long)H;
+        const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 512, r = slot >> 3, kq = (slot & 7) * 4;
+            const int row = min(m0 + r, a.R - 1), k = min(kbase + kq, kval - 4);  // K1, H are multiples of 4 (host-checked)
+            qa[it] = *reinterpret_cast<const f32x4 *>(src + (long)row * ld + k);
+        }
+    };
+    auto split = [&](int ck) {
+        const int k0 = ck * kGemmKC;
+        const bool from_x = k0 < a.K1p;
+        const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 512, r = slot >> 3, kq = (slot & 7) * 4;
+            const bool ok = (m0 + r < a.R) && (kbase + kq < kval);  // 4-aligned windows are either all valid or all padding
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                __bf16 hh, mm, ll;
+                split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
+                pa[it][0][e] = hh; pa[it][1][e] = mm;
+                if (PL > 2) pa[it][PL - 1][e] = ll;
+            }
+        }
+    };
+    const int sw = (l31 >> 2) & 3;  // every fragment row is a multiple of 32 plus l31
+    bf16x8 fa[2][PL];
+    auto load_fa = [&](int ks) {
+        const int slot = (((ks >> 3) + half) ^ sw) * 8;
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int p = 0; p < PL; p++) fa[rt][p] = *reinterpret_cast<const bf16x8 *>(&Ap[p * kLbPlane + (wm + rt * 32 + l31) * kGemmKC + slot]);
+    };
+    auto mfma_gate = [&](int ck, int ks, int g) {  // the 2 x (3 or 6) products of gate g's 32 columns
+        const __bf16 *Wl = Wst + (ck & 1) * PL * kLbPlane;
+        const int slot = (((ks >> 3) + half) ^ sw) * 8;
+        bf16x8 fb[PL];
+#pragma unroll
+        for (int p = 0; p < PL; p++) fb[p] = *reinterpret_cast<const bf16x8 *>(&Wl[p * kLbPlane + (g * kLbU + wn + l31) * kGemmKC + slot]);
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            f32x16 c = acc[rt][g];
+            if (PL > 2) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][1], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][0], fb[PL - 1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][PL - 1], fb[0], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][0], fb[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][1], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt][0], fb[0], c, 0, 0, 0);
+            acc[rt][g] = c;
+        }
+    };
+    dma_w(0);
+    issue(0);
+    split(0);
+#ifdef SE_LSTM_STAMPS
+    unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6, sum[6] = {0, 0, 0, 0, 0, 0};
+#define SE_BSTAMP(t) SE_STAMP(t)
+#else
+#define SE_BSTAMP(t)
+#endif
+    for (int ck = 0; ck < nck; ck++) {
+        SE_BSTAMP(ts0);
+        __syncthreads();  // every wave is done with A(ck - 1) and W stage (ck + 1) & 1
+        SE_BSTAMP(ts1);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 512, r = slot >> 3, kq = (slot & 7) * 4;
+            const int off = r * kGemmKC + (((kq >> 3) ^ ((r >> 2) & 3)) * 8) + (kq & 4);
+#pragma unroll
+            for (int p = 0; p < PL; p++) *reinterpret_cast<bf16x4 *>(&Ap[p * kLbPlane + off]) = pa[it][p];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): this wave's W(ck) DMA (issued one iteration ago) and A stores have landed
+        SE_BSTAMP(ts2);
+        __syncthreads();
+        SE_BSTAMP(ts3);
+        const int nx = min(ck + 1, nck - 1);  // the last iteration re-fetches its own chunk (unused): the loop body stays one basic block
+        // the matrix pipe first: all eight waves leave the barrier together, and 10 x 1 KB of loads per wave queue for ~900 cycles at the
+        // CU's one texture-address unit; behind the first gate's MFMAs that wait is in the pipe's shadow
+        load_fa(0);
+        mfma_gate(ck, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SE_BSTAMP(ts4);
+        dma_w(nx + (nx == ck ? 1 : 0));       // ... into the stage nobody reads
+        issue(nx);
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the operand loads to the end of the iteration (register pressure) and waits on them at once
+        SE_BSTAMP(ts5);
+#pragma unroll
+        for (int g = 1; g < 4; g++) mfma_gate(ck, 0, g);
+        split(nx);
+        load_fa(16);
+#pragma unroll
+        for (int g = 0; g < 4; g++) mfma_gate(ck, 16, g);
+        SE_BSTAMP(ts6);
+#ifdef SE_LSTM_STAMPS
+        sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4; sum[5] += ts6 - ts5;
+#endif
+    }
+#ifdef SE_LSTM_STAMPS
+    if (a.stamps && blockIdx.x == 3 && blockIdx.y == gridDim.y / 2 && tid == 64) {
+        for (int i = 0; i < 6; i++) a.stamps[i] = sum[i];
+        a.stamps[6] = nck;
+    }
+#endif
+    __builtin_amdgcn_s_waitcnt(0x0070);  // drain the dummy DMA before the workgroup's LDS is released
+    // epilogue: torch.nn.LSTM cell, gate order i, f, g, o
+    const int j = h0 + wn + l31;
+    const float bi = a.bias[j], bf = a.bias[H + j], bg = a.bias[2 * H + j], bo = a.bias[3 * H + j];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= a.R) continue;
+            const float ig = 1.0f / (1.0f + expf(-(acc[rt][0][r] + bi)));
+            const float fg = 1.0f / (1.0f + expf(-(acc[rt][1][r] + bf)));
+            const float gg = tanhf(acc[rt][2][r] + bg);
+            const float og = 1.0f / (1.0f + expf(-(acc[rt][3][r] + bo)));
+            const long idx = (long)m * H + j;
+            const float cn = fg * a.c[idx] + ig * gg;
+            const float hn = og * tanhf(cn);
+            a.c[idx] = cn;
+            a.hout[idx] = hn;
+            if (a.hseq) a.hseq[(long)m * a.ldseq + j] = hn;
+        }
 }
 
 // ---- sub-band Linear(H -> 2) for one time step: one wave per row, lanes across k ---------------------------------------------

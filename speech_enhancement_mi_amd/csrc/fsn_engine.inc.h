@@ -21,6 +21,7 @@ struct fsn_engine {
     DevBuf sbinP;  // the unfolded, normalised sub-band input as split-bf16 planes [PL][T][B*F][SI]
     DevBuf spec, maskspec, mag, fb_seq, fb_out, sbin, mask, part_fb, part_sb, mean_fb, mean_sb, denom_fb, denom_sb, yseg;
     int step_fb = 0, step_sb = 0, have_fb = 0, have_sb = 0, nslot_fb = 0, nslot_sb = 0;
+    int lstm_big = 1;     // SE_FSN_BIG=0: keep the 128 x 128 step tiles where the 256-row x 64-unit tile would be picked (read at fsn_create)
     int lstm_planes = 0;  // SE_FSN_PLANES=1: the sub-band LSTM's operands ([x_t | h_{t-1}]) as pre-split bf16 planes written by their producers
                           // (staging = pure copy).  Measured SLOWER than splitting the fp32 operand in the K loop (B = 256: f32 8145 -> 7563,
                           // bf16x3 11163 -> 10729 frames/s): the step is bound by the bytes its 4824 small tiles pull out of L2 (4.7 GB per
@@ -133,6 +134,39 @@ int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, lo
         a.hprev_p = reinterpret_cast<const __bf16 *>(m.hP[l][hc].p);
         a.hout_p = reinterpret_cast<__bf16 *>(m.hP[l][hc ^ 1].p);
         a.x_p = xp; a.x_plane = xplane; a.x_ld = ldx;
+    }
+#ifdef SE_LSTM_STAMPS
+    static unsigned long long *stamps = nullptr;
+    static int nlaunch = 0;
+    if (!stamps) { (void)hipMalloc(&stamps, 64); (void)hipMemset(stamps, 0, 64); }
+    a.stamps = stamps;
+    if (R >= 8192 && ++nlaunch % 997 == 0) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[7];
+        (void)hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost);
+        if (e->lstm_big == 1)
+            fprintf(stderr, "[stamps big] before layer %d: nck %llu per-chunk cycles: barrier1 %.0f store+wait %.0f barrier2 %.0f gate0 %.0f dma+issue %.0f rest %.0f\n", l, h[6],
+                    (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+        else
+            fprintf(stderr, "[stamps] before layer %d: nck %llu per-chunk cycles: barrier1 %.0f vmwait %.0f stage %.0f barrier2 %.0f issue+mfma %.0f\n", l, h[5],
+                    (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+    }
+#endif
+    // big tile (256 rows x 64 units) where it fills the chip: the sub-band model at B >= 32 streams
+    if (e->lstm_big == 1 && !planes && m.H % kLbU == 0 && R >= 32 * kLbM) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lstm_step_big<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lstm_step_big<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        const dim3 gb(m.H / kLbU, (R + kLbM - 1) / kLbM);
+        const int PL = e->c.precision == 2 ? 2 : 3;
+        const size_t lds = (size_t)3 * PL * kLbPlane * sizeof(__bf16);
+        if (PL == 2) hipLaunchKernelGGL((k_lstm_step_big<2>), gb, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((k_lstm_step_big<3>), gb, dim3(512), lds, st, a);
+        m.hcur[l] = hc ^ 1;
+        return 0;
     }
     const dim3 grid((m.H + 31) / 32, (R + kGemmBM - 1) / kGemmBM);
     if (e->c.precision == 2) {
@@ -279,6 +313,7 @@ int fsn_create(const fsn_config *cfg, int device, fsn_engine **out) {
     e->fb.in = cfg->num_freqs * cfg->num_mics; e->fb.inp = e->Kp; e->fb.H = cfg->fb_hidden; e->fb.out = cfg->num_freqs;
     e->sb.in = e->SI; e->sb.inp = (e->SI + 31) & ~31; e->sb.H = cfg->sb_hidden; e->sb.out = 2;
     if (const char *s = getenv("SE_FSN_PLANES")) e->lstm_planes = atoi(s);
+    if (const char *s = getenv("SE_FSN_BIG")) e->lstm_big = atoi(s);
     *out = e;
     return SE_OK;
 }

@@ -431,6 +431,23 @@ def test_fsn_compute_loss_six_arguments():
     assert np.abs(got - lg["loss"]).max() < 1e-4, got
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_fsn_big_tile_lstm_step_equals_128_tiles(prec, monkeypatch):
+    """k_lstm_step_big (256 rows x 64 units per workgroup, picked for the sub-band model from B*F >= 8192 rows) accumulates every
+    element over the same chunks, planes and term order as k_lstm_step_x6's 128 x 128 tiles: same output to rounding at B = 40
+    (R = 40 * 257 = 10 280: 41 row blocks, the last one ragged), and the batch-2 prefix equals a B = 2 run on the small tiles."""
+    from conftest import FSN_FULL
+    mix, _ = synth.synth_utterances(40, 6400, 3, seed=19)
+    x = torch.from_numpy(mix).cuda()
+    big = _fsn_model(FSN_FULL, prec).realtime_process(x, None, False, False).cpu().numpy()
+    monkeypatch.setenv("SE_FSN_BIG", "0")
+    small = _fsn_model(FSN_FULL, prec).realtime_process(x, None, False, False).cpu().numpy()
+    monkeypatch.delenv("SE_FSN_BIG")
+    assert np.isfinite(big).all() and rel_rms(big, small) < 1e-6, rel_rms(big, small)
+    two = _fsn_model(FSN_FULL, prec).realtime_process(x[:2].contiguous(), None, False, False).cpu().numpy()
+    assert rel_rms(big[:2], two) < 1e-6
+
+
 # ---- config 5 in its named dtype at size; the bounded regression guard of the round-2 fault -------------------------------------
 def test_student_batch1024_fp16_named_dtype():
     """BASELINE configs[4] names fp16: precision = 1 (fp16 MFMA operands, fp32 accumulation and storage of the recurrence / norms) at
