@@ -584,6 +584,7 @@ def secondary_lines(args, rank, local_rank):
                         steps=steps, warmup=warmup, dtype=dtype, n_fft=nfft, mflop_per_frame=info["mflop_per_frame"], precision=TOL_NOTE[dtype], roofline=slim)
         return fn
 
+    leg("BASELINE configs[1] (the headline workload) in bf16x3: 3-term split-bf16, pinned at 1e-4 RMS / 0.02 dB against the reference goldens", crn_leg("crn", 256, "bf16x3", 512))
     leg("BASELINE configs[2]: FullSubNet streaming, batch 256, f32", lambda: fullsubnet_line(args, rank, local_rank, 256, "f32", steps=2, warmup=1))
     leg("BASELINE configs[2]: FullSubNet streaming, batch 256, bf16x3", lambda: fullsubnet_line(args, rank, local_rank, 256, "bf16x3", steps=2, warmup=1))
     leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, bf16x3 (inside the parity bar)", crn_leg("student", 1024, "bf16x3", 400))

@@ -70,8 +70,21 @@ __device__ __forceinline__ void convp_stats_store(float *stats, int nslot, int s
     }
 }
 
+// -DSE_CP_TRACE (diagnostic build of the instances of interest + se_engine.hip): thread 0 of every workgroup sums its s_memtime deltas per
+// phase and adds them to a.trace; printed per launch site at process exit.  Read the shares, not the run time of that build.
+#ifdef SE_CP_TRACE
+#define CPT(i) do { unsigned long long _n; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_n) :: "memory"); \
+                    __builtin_amdgcn_sched_barrier(0); tr[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define CPT(i)
+#endif
+
 template <int NTAP, int NT, int CO, int PL>
 __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
+#ifdef SE_CP_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#endif
     // LDS patch [PL][CO][Npos] of 16-byte pieces (plane-major: consecutive LDS-DMA lanes copy consecutive 16-byte pieces of one
     // plane row, i.e. whole cache lines; an interleaved [pos][plane] image made every wave instruction touch three scattered
     // runs and staged at 9 GB/s per CU)
@@ -180,14 +193,18 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
 #pragma unroll
         for (int p = 0; p < PL; p++) bf[p] = *reinterpret_cast<const uint4 *>(ldsb + off + p * plane_bytes);
     };
+    CPT(0);  // prologue: tile geometry + LDS-DMA plan
     for (int ch = 0; ch < a.nchunk; ch++) {
         const uint4 *wc = wxw + ch * wx_chunk;
         uint4 fa_n[PL];
 #pragma unroll
         for (int p = 0; p < PL; p++) fa_n[p] = wc[p * wx_plane];  // first weight fragments of the chunk: in flight during staging
         __syncthreads();  // previous chunk fully consumed
+        CPT(1);
         stage(ch);
+        CPT(2);
         __syncthreads();  // (the compiler drains vmcnt before the barrier: every wave's DMA pieces have landed)
+        CPT(3);
         uint4 bcur[PL], bnxt[PL];
         read_b(0, 0, bcur);
 #pragma unroll
@@ -230,8 +247,21 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
                 for (int p = 0; p < PL; p++) bcur[p] = bnxt[p];
             }
         }
+        CPT(4);  // MFMAs issued (the tail retires inside the next barrier segment)
     }
     __syncthreads();  // LDS is free again (statistics scratch)
+    CPT(1);
+#ifdef SE_CP_TRACE
+    struct TraceOut {  // every epilogue returns: the destructor closes the last segment
+        unsigned long long *tr, &tlast, *out; int tid;
+        __device__ ~TraceOut() {
+            unsigned long long _n;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_n) :: "memory");
+            tr[5] += _n - tlast;
+            if (out && tid == 0) { for (int i = 0; i < 6; i++) atomicAdd(out + i, tr[i]); atomicAdd(out + 7, 1ull); }
+        }
+    } trace_out{tr, tlast, a.trace, tid};
+#endif
 
     // ---- epilogue: lane = position (column of the 32x32 tiles), registers = GEMM rows (r & 3) + 8 (r >> 2) + 4 half ----
     float bv[16];

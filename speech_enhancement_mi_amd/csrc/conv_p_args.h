@@ -21,6 +21,7 @@ struct ConvPArgs {
     int s, colpad, tlo_off, ngroup, dil, grouped, ntap;
     int rowgrp[kMaxTaps], coloff[kMaxTaps];
     int nchunk, tiles_per_wg, St;
+    unsigned long long *trace;  // -DSE_CP_TRACE builds: 8 cycle sums per launch site (nullptr otherwise; never read by the kernel)
     int deint, Sh;          // deint = 1 (stride-2 convolutions): an LDS patch row holds its even columns first, then its odd ones (Sh = (St+1)/2
                             // even slots): column 2m + coloff of lane m becomes slot m + const, a unit-stride ds_read_b128 walk (coloff[] is
                             // then already the slot offset (c & 1) * Sh + (c >> 1)); the HBM layout is unchanged - only the LDS-DMA plan permutes

@@ -190,9 +190,39 @@ void select_convp_geometry(se_engine *e, ConvPPlan &pl) {
     pl.a.tiles_per_wg = g.tpw; pl.a.grouped = g.grouped;
 }
 
-int launch_conv_p(se_engine *e, const ConvPPlan &pl, const ConvPArgs &a, hipStream_t st, const char *label) {
+#ifdef SE_CP_TRACE
+struct CpTraceSites {
+    std::vector<std::pair<std::string, unsigned long long *>> sites;
+    unsigned long long *get(const char *label, int NT, int grid_x) {
+        const std::string key = std::string(label ? label : "?") + " NT=" + std::to_string(NT) + " wg/stream=" + std::to_string(grid_x);
+        for (auto &s : sites) if (s.first == key) return s.second;
+        unsigned long long *p = nullptr;
+        (void)hipMalloc(&p, 64); (void)hipMemset(p, 0, 64);
+        sites.emplace_back(key, p);
+        return p;
+    }
+    void dump() {
+        for (auto &s : sites) {
+            unsigned long long h[8];
+            if (hipMemcpy(h, s.second, sizeof h, hipMemcpyDeviceToHost) != hipSuccess || !h[7]) continue;
+            const double n = (double)h[7];
+            fprintf(stderr, "[cp trace %-34s] %8llu WGs, cycles/WG: prologue %7.0f  barrier1 %7.0f  dma issue %7.0f  barrier2+dma wait %7.0f  mfma loop %7.0f  epilogue %7.0f\n",
+                    s.first.c_str(), h[7], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+            (void)hipMemset(s.second, 0, 64);
+        }
+    }
+};
+static CpTraceSites g_cp_trace_sites;
+#endif
+
+int launch_conv_p(se_engine *e, const ConvPPlan &pl, const ConvPArgs &a_in, hipStream_t st, const char *label) {
     if (!pl.active) return 0;
     ProfScope ps(e, "k_conv_p", label, pl.flops * e->B, st);
+    ConvPArgs a = a_in;
+    a.trace = nullptr;
+#ifdef SE_CP_TRACE
+    a.trace = g_cp_trace_sites.get(label, pl.NT, pl.grid_x);
+#endif
     if (conv_p_launch(a.ntap, pl.NT, pl.CO, operand_planes(e->precision), dim3(pl.grid_x, e->B), pl.lds, st, a))
         return fail(e, SE_ERR_ARG, "no conv_p kernel instance for %d taps x %d tiles x %d octets", a.ntap, pl.NT, pl.CO);
     HIPCHECK(e, hipGetLastError());

@@ -1251,6 +1251,9 @@ void se_destroy(se_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     conv_x6_trace_dump();
+#ifdef SE_CP_TRACE
+    g_cp_trace_sites.dump();
+#endif
     DevBuf *singles[] = {&e->window, &e->env, &e->tw, &e->fcw, &e->fcb, &e->gnw, &e->gnb, &e->maskspec,
                          &e->gru_sync, &e->fcw_x, &e->wih_xp, &e->pre_g, &e->spec_all, &e->mask_all, &e->fc_out, &e->yseg};
     for (DevBuf *b : singles) dev_free(*b);
