@@ -372,7 +372,8 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
             prefetch()
         else:
             mx, tgt = mix, clean
-        last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge)
+        last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge,
+                                  graph_loss=False if getattr(args, "no_graph_loss", False) else None)
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
@@ -645,6 +646,7 @@ def parse_args(argv=None):
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--data", choices=["fixed", "gen"], default="fixed",
                     help="--mode train: fixed = one resident synthetic batch; gen = a fresh batch of simulated rooms per step from the GPU generator")
+    ap.add_argument("--no-graph-loss", action="store_true", help="--mode train: launch the loss's ~150 device ops one by one instead of as a captured HIP graph")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")

@@ -212,7 +212,8 @@ class FlatBucket:
         return norm
 
 
-def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr", merge=None):
+def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr", merge=None,
+               graph_loss=None):
     """One optimizer step of the reference trainer (train.py:195-204) under data parallelism: `accum` micro-batches of local
     utterances, one flat all-reduce, clip 5, Adam.  loss = "full": 0.7 * stoi_loss + 0.3 * (-SI-SNR) (compute_loss,
     CRN.py:609-611); "sisnr": the SI-SNR term alone.
@@ -221,7 +222,10 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     is per utterance, so the `accum` micro-batches can share ONE forward / backward sweep (half the dependent GRU steps) while
     the loss is still formed per micro-batch, sum_i loss(micro-batch i) / accum - the same function of the parameters, hence
     the same gradient up to fp32 summation order (tests/test_gpu_round3.py::test_merged_microbatches_give_the_accumulated_gradient).
-    merge=False runs the micro-batches one after the other like the reference loop."""
+    merge=False runs the micro-batches one after the other like the reference loop.
+
+    graph_loss (default: on with the hand-written kernels): the full loss (STOI + SI-SNR, ~150 small launches) runs as a captured HIP
+    graph per (micro-batch shape), forward and backward (losses.compute_loss_graphed); values and gradient unchanged."""
     bucket.zero()
     total = 0.0
     if merge is None:
@@ -229,17 +233,23 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     srcs = source.chunk(accum)
     lens = [None] * len(srcs) if length is None else list(length.chunk(accum))
 
-    def loss_of(pred, src, ln):
+    if graph_loss is None:
+        graph_loss = model._hip
+
+    def loss_of(pred, src, ln, slot=0):
         if loss == "full":
             ll = ln if ln is not None else torch.full((pred.shape[0],), pred.shape[-1], dtype=torch.int64, device=pred.device)
+            if graph_loss and pred.is_cuda:
+                from .losses import compute_loss_graphed
+                return compute_loss_graphed(src.contiguous(), pred.contiguous(), ll.to(torch.int64), slot=slot)[0] / accum
             return model.compute_loss(src, pred, ll)[0] / accum
         return si_snr_loss(pred, src, ln) / accum
 
     if merge:
         pred = model.realtime_process_train(mixture)
         val = None
-        for p_i, src, ln in zip(pred.chunk(accum), srcs, lens):
-            v = loss_of(p_i, src, ln)
+        for slot, (p_i, src, ln) in enumerate(zip(pred.chunk(accum), srcs, lens)):
+            v = loss_of(p_i, src, ln, slot)
             val = v if val is None else val + v
         val.backward()
         total = float(val.detach())

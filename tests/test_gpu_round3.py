@@ -448,6 +448,25 @@ def test_fsn_big_tile_lstm_step_equals_128_tiles(prec, monkeypatch):
     assert rel_rms(big[:2], two) < 1e-6
 
 
+def test_graphed_loss_equals_eager_loss_and_gradient():
+    """losses.compute_loss_graphed (forward + backward captured once per shape, replayed) gives the eager compute_loss's three values and
+    its gradient w.r.t. the prediction, also on the replay with NEW inputs and ragged lengths (the graph holds no input-dependent shape)."""
+    from speech_enhancement_mi_amd import losses
+    mix, clean = synth.synth_utterances(4, 24000, 3, seed=23)
+    for trial, lens in enumerate(([24000, 24000, 24000, 24000], [24000, 17001, 9000, 20000])):
+        src = torch.from_numpy(np.roll(clean, 100 * trial, axis=1).copy()).cuda()
+        noise = torch.from_numpy(mix[:, 0].copy()).cuda()
+        ln = torch.tensor(lens, dtype=torch.int64, device="cuda")
+        res = []
+        for fn in (losses.compute_loss, losses.compute_loss_graphed):
+            pred = (0.6 * src + 0.4 * noise).requires_grad_()
+            out = fn(src, pred, ln)
+            out[0].backward()
+            res.append((torch.stack(list(out)).detach().cpu().double(), pred.grad.detach().cpu().double()))
+        assert (res[0][0] - res[1][0]).abs().max() < 1e-6, (trial, res[0][0], res[1][0])
+        assert _rel(res[1][1], res[0][1]) < 1e-5, trial
+
+
 # ---- config 5 in its named dtype at size; the bounded regression guard of the round-2 fault -------------------------------------
 def test_student_batch1024_fp16_named_dtype():
     """BASELINE configs[4] names fp16: precision = 1 (fp16 MFMA operands, fp32 accumulation and storage of the recurrence / norms) at
