@@ -21,6 +21,11 @@ struct fsn_engine {
     DevBuf sbinP;  // the unfolded, normalised sub-band input as split-bf16 planes [PL][T][B*F][SI]
     DevBuf spec, maskspec, mag, fb_seq, fb_out, sbin, mask, part_fb, part_sb, mean_fb, mean_sb, denom_fb, denom_sb, yseg;
     int step_fb = 0, step_sb = 0, have_fb = 0, have_sb = 0, nslot_fb = 0, nslot_sb = 0;
+    // realtime_process: the full-band model of window n + 1 runs on `side` while the sub-band model of window n runs on the caller's stream
+    // (the full-band recurrence is 42 launches of 32 workgroups per window, 11 % of the serial time, latency-bound: profiles/r03_fsn_*)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[2]{}, ev_consumed[2]{}, ev_done[2]{}, ev_fork = nullptr;
+    int pipeline = 1;     // SE_FSN_PIPELINE=0: one stream, stage after stage (read at fsn_create)
     int lstm_big = 1;     // SE_FSN_BIG=0: keep the 128 x 128 step tiles where the 256-row x 64-unit tile would be picked (read at fsn_create)
     int lstm_planes = 0;  // SE_FSN_PLANES=1: the sub-band LSTM's operands ([x_t | h_{t-1}]) as pre-split bf16 planes written by their producers
                           // (staging = pure copy).  Measured SLOWER than splitting the fp32 operand in the K loop (B = 256: f32 8145 -> 7563,
@@ -181,10 +186,9 @@ int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, lo
 }
 
 // forward on device.  Spectrum given by (re, im) pointers + strides in float units for (b, m, t, f).
-int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, long sM, long sT, long sF, float *crm_out, cf2 *spec_out,
-                    long oB, long oT, long oF, hipStream_t st) {
-    const int B = e->B, T = e->T, F = e->F, M = e->M, Kp = e->Kp, SI = e->SI;
-    const int R = B * F;
+// Stage A of a window: |X|, its CumLayerNorm, the full-band LSTM and its output layer -> e->mag, e->fb_out (read by stage B's unfold only)
+int fsn_stage_fb(fsn_engine *e, const float *re, const float *im, long sB, long sM, long sT, long sF, hipStream_t st) {
+    const int B = e->B, T = e->T, F = e->F, M = e->M, Kp = e->Kp;
     {  // |X| + CumLayerNorm of the full-band input (fullsubnet.py:782-788)
         FsnMagArgs a{re, im, sB, sM, sT, sF, e->mag.p, e->part_fb.p, M, T, F, Kp};
         hipLaunchKernelGGL(k_fsn_mag, dim3(e->nslot_fb, B), dim3(256), 0, st, a);
@@ -209,9 +213,20 @@ int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, lo
         GemmX6Args g{e->fb_seq.p, reinterpret_cast<const __bf16 *>(e->fb.fcw_x.p), e->fb.fcb.p, e->fb_out.p, B * T, F, e->fb.H, (long)e->fb.H, (long)F, 1};
         hipLaunchKernelGGL(k_gemm_x<3>, dim3((F + kGemmBN - 1) / kGemmBN, (B * T + kGemmBM - 1) / kGemmBM), dim3(256), 0, st, g);
     }
+    FHIP(e, hipGetLastError());
+    return 0;
+}
+
+// Stage B: sub-band input, its CumLayerNorm, the sub-band LSTM over B*F rows, mask.  `consumed` (optional) is recorded once e->mag / e->fb_out
+// have been read, i.e. when the next window's stage A may overwrite them.
+int fsn_stage_sb(fsn_engine *e, const float *re, const float *im, long sB, long sT, long sF, float *crm_out, cf2 *spec_out,
+                 long oB, long oT, long oF, hipStream_t st, hipEvent_t consumed) {
+    const int B = e->B, T = e->T, F = e->F, Kp = e->Kp, SI = e->SI;
+    const int R = B * F;
     {  // sub-band input + its CumLayerNorm (fullsubnet.py:796-802)
         FsnUnfoldArgs a{e->mag.p, e->fb_out.p, e->sbin.p, e->part_sb.p, B, T, F, Kp, e->c.sb_neighbors, SI};
         hipLaunchKernelGGL(k_fsn_unfold, dim3(e->nslot_sb, B), dim3(256), 0, st, a);
+        if (consumed) FHIP(e, hipEventRecord(consumed, st));
         const float alpha = (float)e->step_sb / (float)(e->step_sb + 1);
         hipLaunchKernelGGL(k_fsn_runmean, dim3((B + 255) / 256), dim3(256), 0, st, e->part_sb.p, e->nslot_sb, (double)F * SI * T, e->mean_sb.p,
                            e->denom_sb.p, B, e->have_sb ? 0 : 1, alpha);
@@ -241,6 +256,13 @@ int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, lo
     return 0;
 }
 
+int fsn_forward_dev(fsn_engine *e, const float *re, const float *im, long sB, long sM, long sT, long sF, float *crm_out, cf2 *spec_out,
+                    long oB, long oT, long oF, hipStream_t st) {
+    int rc;
+    if ((rc = fsn_stage_fb(e, re, im, sB, sM, sT, sF, st))) return rc;
+    return fsn_stage_sb(e, re, im, sB, sT, sF, crm_out, spec_out, oB, oT, oF, st, nullptr);
+}
+
 int fsn_reset_on(fsn_engine *e, int batch, hipStream_t st) {
     if (!e || batch <= 0) return ffail(e, SE_ERR_ARG, "batch must be positive");
     FHIP(e, hipSetDevice(e->device));
@@ -250,7 +272,8 @@ int fsn_reset_on(fsn_engine *e, int batch, hipStream_t st) {
     e->B = B;
     e->nslot_fb = 8;
     e->nslot_sb = 32;
-    if ((rc = falloc(e, e->spec, (size_t)B * M * T * F * 2)) || (rc = falloc(e, e->maskspec, (size_t)B * T * F * 2)) ||
+    // spec holds two windows: stage A of window n + 1 transforms while stage B of window n still masks its spectrum
+    if ((rc = falloc(e, e->spec, (size_t)2 * B * M * T * F * 2)) || (rc = falloc(e, e->maskspec, (size_t)B * T * F * 2)) ||
         (rc = falloc(e, e->mag, (size_t)B * T * e->Kp)) || (rc = falloc(e, e->fb_seq, (size_t)B * T * e->fb.H)) ||
         (rc = falloc(e, e->fb_out, (size_t)B * T * F)) || (rc = falloc(e, e->sbin, (size_t)T * R * e->SI)) ||
         (e->lstm_planes && (rc = falloc(e, e->sbinP, ((size_t)3 * T * R * e->SI + 1) / 2))) ||
@@ -314,6 +337,17 @@ int fsn_create(const fsn_config *cfg, int device, fsn_engine **out) {
     e->sb.in = e->SI; e->sb.inp = (e->SI + 31) & ~31; e->sb.H = cfg->sb_hidden; e->sb.out = 2;
     if (const char *s = getenv("SE_FSN_PLANES")) e->lstm_planes = atoi(s);
     if (const char *s = getenv("SE_FSN_BIG")) e->lstm_big = atoi(s);
+    if (const char *s = getenv("SE_FSN_PIPELINE")) e->pipeline = atoi(s);
+    if (e->pipeline) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        bool ok = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, hi) == hipSuccess;  // the short full-band launches go first when a CU frees up
+        ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && ok; i++)
+            ok = hipEventCreateWithFlags(&e->ev_ready[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->ev_consumed[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { fsn_destroy(e); return ffail(nullptr, SE_ERR_HIP, "fsn_create: side stream / events: %s", hipGetErrorString(hipGetLastError())); }
+    }
     *out = e;
     return SE_OK;
 }
@@ -330,6 +364,9 @@ void fsn_destroy(fsn_engine *e) {
                       &e->mean_sb, &e->denom_fb, &e->denom_sb, &e->yseg})
         dev_free(*b);
     dev_free(e->sbinP);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    for (hipEvent_t ev : {e->ev_fork, e->ev_ready[0], e->ev_ready[1], e->ev_consumed[0], e->ev_consumed[1], e->ev_done[0], e->ev_done[1]})
+        if (ev) (void)hipEventDestroy(ev);
     se_destroy(e->sig);
     delete e;
 }
@@ -391,13 +428,31 @@ int fsn_realtime_process(fsn_engine *e, const float *mixture, int batch, int64_t
     const long F = e->F, T = e->T, M = e->M;
     cf2 *spec = reinterpret_cast<cf2 *>(e->spec.p);
     cf2 *ms = reinterpret_cast<cf2 *>(e->maskspec.p);
+    const size_t spec_floats = (size_t)batch * M * T * F * 2;
+    const bool piped = e->pipeline && e->side && Nseg > 1;
+    hipStream_t sa = piped ? e->side : st;
+    if (piped) {  // the side stream starts after whatever the caller's stream holds (reset, the previous call's tail)
+        FHIP(e, hipEventRecord(e->ev_fork, st));
+        FHIP(e, hipStreamWaitEvent(sa, e->ev_fork, 0));
+    }
     for (long n = 0; n < Nseg; n++) {
         const long off = n * P - P - lead;
-        if (launch_stft(e->sig, mixture, (long)M * length, length, (int)M, off, length, batch * (int)M, spec, T * F, F, 1, st))
+        const int slot = piped ? (int)(n & 1) : 0;
+        const float *sp = e->spec.p + slot * spec_floats;
+        if (piped) {
+            if (n >= 2) FHIP(e, hipStreamWaitEvent(sa, e->ev_done[slot], 0));          // window n - 2 has masked spectrum[slot]
+            if (n >= 1) FHIP(e, hipStreamWaitEvent(sa, e->ev_consumed[slot ^ 1], 0));  // window n - 1 has unfolded mag / fb_out
+        }
+        if (launch_stft(e->sig, mixture, (long)M * length, length, (int)M, off, length, batch * (int)M, spec + slot * (spec_floats / 2), T * F, F, 1, sa))
             return ffail(e, SE_ERR_HIP, "stft: %s", se_last_error(e->sig));
-        const float *sp = e->spec.p;
-        if ((rc = fsn_forward_dev(e, sp, sp + 1, 2 * M * T * F, 2 * T * F, 2 * F, 2, nullptr, ms, T * F, F, 1, st))) return rc;
+        if ((rc = fsn_stage_fb(e, sp, sp + 1, 2 * M * T * F, 2 * T * F, 2 * F, 2, sa))) return rc;
+        if (piped) {
+            FHIP(e, hipEventRecord(e->ev_ready[slot], sa));
+            FHIP(e, hipStreamWaitEvent(st, e->ev_ready[slot], 0));
+        }
+        if ((rc = fsn_stage_sb(e, sp, sp + 1, 2 * M * T * F, 2 * F, 2, nullptr, ms, T * F, F, 1, st, piped ? e->ev_consumed[slot] : nullptr))) return rc;
         if (launch_istft(e->sig, ms, T * F, F, 1, batch, e->yseg.p + n * K, Nseg * K, st)) return ffail(e, SE_ERR_HIP, "istft: %s", se_last_error(e->sig));
+        if (piped) FHIP(e, hipEventRecord(e->ev_done[slot], st));
     }
     launch_k_overlap_avg(dim3((unsigned)((length + 255) / 256), batch), st, e->yseg.p, out, (int)Nseg, (int)K, (long)length, lead);
     FHIP(e, hipGetLastError());

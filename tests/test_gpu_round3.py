@@ -467,6 +467,25 @@ def test_graphed_loss_equals_eager_loss_and_gradient():
         assert _rel(res[1][1], res[0][1]) < 1e-5, trial
 
 
+def test_fsn_window_pipeline_is_bit_identical_to_one_stream(monkeypatch):
+    """fsn_realtime_process runs the full-band model of window n + 1 on a side stream while the sub-band model of window n runs on the
+    caller's stream (events guard mag / fb_out / the two-slot spectrum ring).  Same kernels, same order per buffer: the output, also of a
+    flag=True continuation, is bit-identical to SE_FSN_PIPELINE=0."""
+    from conftest import FSN_FULL
+    mix, _ = synth.synth_utterances(3, 9600 + 6400, 3, seed=29)
+    x = torch.from_numpy(mix).cuda()
+    outs = []
+    for piped in (True, False):
+        if not piped:
+            monkeypatch.setenv("SE_FSN_PIPELINE", "0")
+        m = _fsn_model(FSN_FULL)
+        y1 = m.realtime_process(x[..., :9600].contiguous(), None, False, False).cpu().numpy()
+        y2 = m.realtime_process(x[..., 9600:].contiguous(), None, True, False).cpu().numpy()
+        outs.append((y1, y2))
+    monkeypatch.delenv("SE_FSN_PIPELINE")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 # ---- config 5 in its named dtype at size; the bounded regression guard of the round-2 fault -------------------------------------
 def test_student_batch1024_fp16_named_dtype():
     """BASELINE configs[4] names fp16: precision = 1 (fp16 MFMA operands, fp32 accumulation and storage of the recurrence / norms) at
