@@ -25,6 +25,10 @@ struct fsn_engine {
     // (the full-band recurrence is 42 launches of 32 workgroups per window, 11 % of the serial time, latency-bound: profiles/r03_fsn_*)
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[2]{}, ev_consumed[2]{}, ev_done[2]{}, ev_fork = nullptr;
+    // ... and inside stage B the sub-band model's layer 1 runs one time step behind layer 0 on `side2`: both launches are 4.7 rounds of
+    // one-workgroup-per-CU tiles, the second fills the first one's last round
+    hipStream_t side2 = nullptr;
+    std::vector<hipEvent_t> ev_l0, ev_l1;  // per time step: layer 0 / layer 1 (+ its output layer) done
     int pipeline = 1;     // SE_FSN_PIPELINE=0: one stream, stage after stage (read at fsn_create)
     int lstm_big = 1;     // SE_FSN_BIG=0: keep the 128 x 128 step tiles where the 256-row x 64-unit tile would be picked (read at fsn_create)
     int lstm_planes = 0;  // SE_FSN_PLANES=1: the sub-band LSTM's operands ([x_t | h_{t-1}]) as pre-split bf16 planes written by their producers
@@ -236,17 +240,27 @@ int fsn_stage_sb(fsn_engine *e, const float *re, const float *im, long sB, long 
                            (e->lstm_planes && e->sbinP.p) ? reinterpret_cast<__bf16 *>(e->sbinP.p) : nullptr, e->c.precision == 2 ? 2 : 3);
         FHIP(e, hipGetLastError());
     }
+    // two layers (the reference configuration) on two streams: layer 0 of step t + 1 next to layer 1 of step t.  h of layer 0 ping-pongs
+    // between two buffers: step t + 2 of layer 0 overwrites what layer 1 of step t reads, hence ev_l1[t].
+    const bool wave = consumed != nullptr && e->side2 && e->NL == 2 && (int)e->ev_l0.size() >= T && !e->lstm_planes;
     for (int t = 0; t < T; t++) {  // sub-band LSTM over B*F rows + Linear(H -> 2)  (fullsubnet.py:812-814)
         for (int l = 0; l < e->NL; l++) {
             const bool pl_ok = e->lstm_planes && e->sbinP.p && SI % 32 == 0;
-            if (l == 0) fsn_lstm_step(e, e->sb, 0, e->sbin.p + (long)t * R * SI, SI, SI, (SI + 31) & ~31, R, nullptr, 0, st,
+            hipStream_t sl = wave && l == 1 ? e->side2 : st;
+            if (wave && l == 0 && t >= 2) FHIP(e, hipStreamWaitEvent(st, e->ev_l1[t - 2], 0));
+            if (wave && l == 1) FHIP(e, hipStreamWaitEvent(sl, e->ev_l0[t], 0));
+            if (l == 0) fsn_lstm_step(e, e->sb, 0, e->sbin.p + (long)t * R * SI, SI, SI, (SI + 31) & ~31, R, nullptr, 0, sl,
                                       pl_ok ? reinterpret_cast<const __bf16 *>(e->sbinP.p) + (long)t * R * SI : nullptr, (long)T * R * SI);
-            else fsn_lstm_step(e, e->sb, l, e->sb.h[l - 1][e->sb.hcur[l - 1]].p, e->sb.H, e->sb.H, (e->sb.H + 31) & ~31, R, nullptr, 0, st,
+            else fsn_lstm_step(e, e->sb, l, e->sb.h[l - 1][e->sb.hcur[l - 1]].p, e->sb.H, e->sb.H, (e->sb.H + 31) & ~31, R, nullptr, 0, sl,
                                pl_ok ? reinterpret_cast<const __bf16 *>(e->sb.hP[l - 1][e->sb.hcur[l - 1]].p) : nullptr, (long)R * e->sb.H);
+            if (wave && l == 0) FHIP(e, hipEventRecord(e->ev_l0[t], st));
         }
         const int ll = e->NL - 1;
-        hipLaunchKernelGGL(k_fsn_sbfc, dim3(2048), dim3(256), 0, st, e->sb.h[ll][e->sb.hcur[ll]].p, e->sb.fcw.p, e->sb.fcb.p, e->mask.p, R, e->sb.H, T, t);
+        hipStream_t so = wave ? e->side2 : st;
+        hipLaunchKernelGGL(k_fsn_sbfc, dim3(2048), dim3(256), 0, so, e->sb.h[ll][e->sb.hcur[ll]].p, e->sb.fcw.p, e->sb.fcb.p, e->mask.p, R, e->sb.H, T, t);
+        if (wave) FHIP(e, hipEventRecord(e->ev_l1[t], so));
     }
+    if (wave) FHIP(e, hipStreamWaitEvent(st, e->ev_l1[T - 1], 0));  // join: the mask needs every step's output
     FHIP(e, hipGetLastError());
     {
         FsnMaskArgs a{e->mask.p, spec_out ? re : nullptr, spec_out ? im : nullptr, sB, sT, sF, spec_out, oB, oT, oF, crm_out, T, F};
@@ -346,6 +360,10 @@ int fsn_create(const fsn_config *cfg, int device, fsn_engine **out) {
         for (int i = 0; i < 2 && ok; i++)
             ok = hipEventCreateWithFlags(&e->ev_ready[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->ev_consumed[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess;
+        e->ev_l0.assign(e->T, nullptr); e->ev_l1.assign(e->T, nullptr);
+        for (int t = 0; t < e->T && ok; t++)
+            ok = hipEventCreateWithFlags(&e->ev_l0[t], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->ev_l1[t], hipEventDisableTiming) == hipSuccess;
         if (!ok) { fsn_destroy(e); return ffail(nullptr, SE_ERR_HIP, "fsn_create: side stream / events: %s", hipGetErrorString(hipGetLastError())); }
     }
     *out = e;
@@ -365,6 +383,9 @@ void fsn_destroy(fsn_engine *e) {
         dev_free(*b);
     dev_free(e->sbinP);
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->side2) (void)hipStreamDestroy(e->side2);
+    for (hipEvent_t ev : e->ev_l0) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_l1) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->ev_fork, e->ev_ready[0], e->ev_ready[1], e->ev_consumed[0], e->ev_consumed[1], e->ev_done[0], e->ev_done[1]})
         if (ev) (void)hipEventDestroy(ev);
     se_destroy(e->sig);
