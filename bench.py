@@ -415,7 +415,7 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
 
 
 def train_line(args, rank, local_rank, train_model="crn"):
-    r = train_measure(args, rank, local_rank, 1, "none", steps=3, warmup=2, train_model=train_model)
+    r = train_measure(args, rank, local_rank, 1, "none", steps=8, warmup=3, train_model=train_model)
     return {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} | dict(workload=r["config"]["workload"])
 
 
@@ -586,8 +586,8 @@ def secondary_lines(args, rank, local_rank):
         return fn
 
     leg("BASELINE configs[1] (the headline workload) in bf16x3: 3-term split-bf16, pinned at 1e-4 RMS / 0.02 dB against the reference goldens", crn_leg("crn", 256, "bf16x3", 512))
-    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, f32", lambda: fullsubnet_line(args, rank, local_rank, 256, "f32", steps=2, warmup=1))
-    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, bf16x3", lambda: fullsubnet_line(args, rank, local_rank, 256, "bf16x3", steps=2, warmup=1))
+    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, f32", lambda: fullsubnet_line(args, rank, local_rank, 256, "f32", steps=3, warmup=1))
+    leg("BASELINE configs[2]: FullSubNet streaming, batch 256, bf16x3", lambda: fullsubnet_line(args, rank, local_rank, 256, "bf16x3", steps=3, warmup=1))
     leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, bf16x3 (inside the parity bar)", crn_leg("student", 1024, "bf16x3", 400))
     leg("BASELINE configs[4]: distilled CRN_ELU student, batch 1024, f16 (the config's named dtype; outside the parity bar)", crn_leg("student", 1024, "f16", 400))
     leg("CRN_ELU (the variant train.py trains) streaming, batch 256, f32", crn_leg("crn_elu", 256, "f32", 400))
