@@ -323,7 +323,10 @@ template <int PL>
 __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
     extern __shared__ __align__(16) unsigned char lstm_lds[];
     __bf16 *Wst = reinterpret_cast<__bf16 *>(lstm_lds);            // [2][PL][256 rows][32]
-    __bf16 *Ap = Wst + 2 * PL * kLbPlane;                           // [PL][256 rows][32]
+    __bf16 *Ast = Wst + 2 * PL * kLbPlane;                          // [1 or 2][PL][256 rows][32]
+    // bf16x3 (PL = 2): the A stage is double-buffered too (128 KB in all), the stores of chunk ck + 1 go out between the MFMA groups of
+    // chunk ck and ONE barrier per chunk is left; with three planes a second A stage does not fit (192 KB)
+    constexpr bool kOneBarrier = PL == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = (wave & 3) * 64, wn = (wave >> 2) * 32;
@@ -391,12 +394,23 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
     };
     const int sw = (l31 >> 2) & 3;  // every fragment row is a multiple of 32 plus l31
     bf16x8 fa[2][PL];
-    auto load_fa = [&](int ks) {
+    auto load_fa = [&](int ck, int ks) {
+        const __bf16 *Ap = Ast + (kOneBarrier ? (ck & 1) * PL * kLbPlane : 0);
         const int slot = (((ks >> 3) + half) ^ sw) * 8;
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
             for (int p = 0; p < PL; p++) fa[rt][p] = *reinterpret_cast<const bf16x8 *>(&Ap[p * kLbPlane + (wm + rt * 32 + l31) * kGemmKC + slot]);
+    };
+    auto store_a = [&](int ck) {  // the split values of chunk ck (in pa) -> its A stage
+        __bf16 *Ap = Ast + (kOneBarrier ? (ck & 1) * PL * kLbPlane : 0);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int slot = tid + it * 512, r = slot >> 3, kq = (slot & 7) * 4;
+            const int off = r * kGemmKC + (((kq >> 3) ^ ((r >> 2) & 3)) * 8) + (kq & 4);
+#pragma unroll
+            for (int p = 0; p < PL; p++) *reinterpret_cast<bf16x4 *>(&Ap[p * kLbPlane + off]) = pa[it][p];
+        }
     };
     auto mfma_gate = [&](int ck, int ks, int g) {  // the 2 x (3 or 6) products of gate g's 32 columns
         const __bf16 *Wl = Wst + (ck & 1) * PL * kLbPlane;
@@ -421,6 +435,38 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
     dma_w(0);
     issue(0);
     split(0);
+    if constexpr (kOneBarrier) {
+        store_a(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+        for (int ck = 0; ck < nck; ck++) {
+            const int nx = min(ck + 1, nck - 1);  // the last iteration re-fetches its own chunk into the stages nobody reads
+            const int nst = ck + 1;               // stage parity of the chunk being prepared (also on the last, unused, round)
+            load_fa(ck, 0);
+            mfma_gate(ck, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // W(ck + 1) -> W stage (ck + 1) & 1, read last in iteration ck - 1: every wave is past that iteration's barrier
+                __bf16 *dst = Wst + (nst & 1) * PL * kLbPlane;
+#pragma unroll
+                for (int j = 0; j < 2 * PL; j++) {
+                    const unsigned v = woff[j];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(dst + (j >> 1) * kLbPlane + (wave + 8 * (j & 1)) * 16 * kGemmKC), 16,
+                                                             v, nx * kGemmKC * 2, 0, 0);
+                }
+            }
+            issue(nx);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 1; g < 4; g++) mfma_gate(ck, 0, g);
+            split(nx);
+            store_a(nst);
+            load_fa(ck, 16);
+#pragma unroll
+            for (int g = 0; g < 4; g++) mfma_gate(ck, 16, g);
+            __builtin_amdgcn_s_waitcnt(0x0070);  // this wave's W(ck + 1) DMA and A(ck + 1) stores have landed
+            __syncthreads();
+        }
+    } else {
 #ifdef SE_LSTM_STAMPS
     unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6, sum[6] = {0, 0, 0, 0, 0, 0};
 #define SE_BSTAMP(t) SE_STAMP(t)
@@ -431,13 +477,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
         SE_BSTAMP(ts0);
         __syncthreads();  // every wave is done with A(ck - 1) and W stage (ck + 1) & 1
         SE_BSTAMP(ts1);
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int slot = tid + it * 512, r = slot >> 3, kq = (slot & 7) * 4;
-            const int off = r * kGemmKC + (((kq >> 3) ^ ((r >> 2) & 3)) * 8) + (kq & 4);
-#pragma unroll
-            for (int p = 0; p < PL; p++) *reinterpret_cast<bf16x4 *>(&Ap[p * kLbPlane + off]) = pa[it][p];
-        }
+        store_a(ck);
         __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): this wave's W(ck) DMA (issued one iteration ago) and A stores have landed
         SE_BSTAMP(ts2);
         __syncthreads();
@@ -445,7 +485,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
         const int nx = min(ck + 1, nck - 1);  // the last iteration re-fetches its own chunk (unused): the loop body stays one basic block
         // the matrix pipe first: all eight waves leave the barrier together, and 10 x 1 KB of loads per wave queue for ~900 cycles at the
         // CU's one texture-address unit; behind the first gate's MFMAs that wait is in the pipe's shadow
-        load_fa(0);
+        load_fa(ck, 0);
         mfma_gate(ck, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         SE_BSTAMP(ts4);
@@ -456,7 +496,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
 #pragma unroll
         for (int g = 1; g < 4; g++) mfma_gate(ck, 0, g);
         split(nx);
-        load_fa(16);
+        load_fa(ck, 16);
 #pragma unroll
         for (int g = 0; g < 4; g++) mfma_gate(ck, 16, g);
         SE_BSTAMP(ts6);
@@ -470,6 +510,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_big(LstmStepArgs a) {
         a.stamps[6] = nck;
     }
 #endif
+    }
     __builtin_amdgcn_s_waitcnt(0x0070);  // drain the dummy DMA before the workgroup's LDS is released
     // epilogue: torch.nn.LSTM cell, gate order i, f, g, o
     const int j = h0 + wn + l31;

@@ -171,7 +171,7 @@ int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, lo
         }
         const dim3 gb(m.H / kLbU, (R + kLbM - 1) / kLbM);
         const int PL = e->c.precision == 2 ? 2 : 3;
-        const size_t lds = (size_t)3 * PL * kLbPlane * sizeof(__bf16);
+        const size_t lds = (size_t)(PL == 2 ? 4 : 3) * PL * kLbPlane * sizeof(__bf16);  // bf16x3: both operands double-buffered
         if (PL == 2) hipLaunchKernelGGL((k_lstm_step_big<2>), gb, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((k_lstm_step_big<3>), gb, dim3(512), lds, st, a);
         m.hcur[l] = hc ^ 1;
