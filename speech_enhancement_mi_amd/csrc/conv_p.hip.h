@@ -138,31 +138,16 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
     const int NI = (items + 255) >> 8;
     unsigned voff[kPNiMax];  // byte offset of chunk 0's source piece, or kPOob for the zero halo
     {
-        const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
-        const float invNpos = 1.0f / (float)Npos, invSt = 1.0f / (float)St, invRTp = 1.0f / (float)RTp;
-        const long tf = (long)a.T * a.Fi;
-        const long sb = (long)b * a.C8 * PL * tf;
+        const long sb = (long)b * a.C8 * PL * a.T * a.Fi;
+        const unsigned base_cur = (unsigned)((a.cur_off + sb) * 16), base_prev = (unsigned)((a.prev_off + sb) * 16);
+        const unsigned *pt = a.plan + (long)blockIdx.x * (kPNiMax * 256) + tid;
 #pragma unroll
         for (int k = 0; k < kPNiMax; k++) {
             voff[k] = kPOob;
             if (k < NI) {
-                const int it = tid + 256 * k;
-                if (it < items) {
-                    const int q = (int)(((float)it + 0.5f) * invNpos);  // LDS slot = (pl * CO + oc) * Npos + pe
-                    const int pe = it - q * Npos;
-                    const int pl = q / CO, oc = q - pl * CO;
-                    const int r = (int)(((float)pe + 0.5f) * invSt), slot = pe - r * St;
-                    const int col = a.deint ? (slot < a.Sh ? 2 * slot : 2 * (slot - a.Sh) + 1) : slot;  // even columns first, then the odd ones
-                    const int g = NGp > 1 ? (int)(((float)r + 0.5f) * invRTp) : 0, j = r - g * RTp;
-                    const int ts = ta + a.tlo_off + g * a.dil + j;
-                    const int fi = col - a.colpad;
-                    const bool hist = ts < 0;
-                    const bool ok = fi >= 0 && fi < a.Fi && (hist ? (a.prev_off >= 0 && ts + a.T >= 0) : ts < a.T);
-                    if (ok) {
-                        const long e = (hist ? a.prev_off : a.cur_off) + sb + ((long)(oc * PL + pl) * a.T + (hist ? ts + a.T : ts)) * a.Fi + fi;
-                        voff[k] = (unsigned)(e * 16);
-                    }
-                }
+                const unsigned t = pt[k * 256];
+                const bool hist = (t >> 31) != 0;
+                if (t != kPOob && !(hist && a.prev_off < 0)) voff[k] = (hist ? base_prev : base_cur) + (t & 0x7FFFFFFFu);
             }
         }
     }
