@@ -98,19 +98,12 @@ __global__ __launch_bounds__(256) void k_fsn_unfold(FsnUnfoldArgs a) {
 }
 
 // sbin is time-major, so the per-stream scale cannot use k_fsn_scale's contiguous layout
-__global__ void k_fsn_scale_sb(float *sbin, int B, int T, int F, int SI, const float *denom, __bf16 *planes, int PL) {
+__global__ void k_fsn_scale_sb(float *sbin, int B, int T, int F, int SI, const float *denom) {
     const long per_t = (long)B * F * SI, total = per_t * T;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i % per_t;
         const int b = (int)(r / ((long)F * SI));
-        const float v = sbin[i] / denom[b];
-        sbin[i] = v;
-        if (planes) {  // the sub-band LSTM's layer-0 operand, pre-split: [PL][T][B*F][SI]
-            __bf16 hh, mm, ll;
-            split3(v, hh, mm, ll);
-            planes[i] = hh; planes[total + i] = mm;
-            if (PL > 2) planes[2 * total + i] = ll;
-        }
+        sbin[i] = sbin[i] / denom[b];
     }
 }
 
@@ -127,14 +120,6 @@ struct LstmStepArgs {
     float *hseq;       // optional second copy of h (row stride ldseq), nullptr = off
     long ldseq;
     int R, H;
-    // Round 3: the recurrent operand also lives as split-bf16 planes [PL][R][H], written by the cell epilogue of the previous step
-    // (hout_p) and staged as a pure copy (hprev_p; x_p = the layer below's planes of THIS step for layers >= 1).  Without them every
-    // one of the H/32 column workgroups re-splits the same fp32 rows in the K loop: ~200 VALU instructions per 32-deep chunk per
-    // thread next to 24 (bf16x3) or 48 MFMAs - the split, not the matrix pipe, bounded the 3-term mode.  nullptr = fp32 operand, split here.
-    const __bf16 *hprev_p, *x_p;
-    __bf16 *hout_p;
-    long p_plane;      // elements per plane of hprev_p / hout_p (R * H)
-    long x_plane, x_ld; // elements per plane and row stride of x_p (layer 0: the unfolded input planes [PL][R][SI]; layers >= 1: R * H, H)
 #ifdef SE_LSTM_STAMPS
     unsigned long long *stamps;  // diagnostic build only: per-segment cycle sums of one wave (never read by the kernel)
 #endif
@@ -145,8 +130,9 @@ struct LstmStepArgs {
 #endif
 
 // PL = operand planes: 3 = fp32-accurate (six products), 2 = "bf16x3" (hi, mid: three products, fsn_config.precision = 2)
-// PLANES = the A operand ([x_t | h_{t-1}]) arrives pre-split (x_p, hprev_p): staging is a pure copy; false = fp32 operand split in the loop
-template <int PL, bool PLANES>
+// (A variant that staged [x_t | h_{t-1}] from pre-split planes written by the producers - a pure copy, no VALU split in the loop - was
+//  7 % / 4 % slower: 1.5x the operand bytes, and the split was never the wait, see k_lstm_step_big's header.)
+template <int PL>
 __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
     __shared__ __align__(16) __bf16 Ap[PL][kGemmBM * kXLd];
     __shared__ __align__(16) __bf16 Wl[PL][kGemmBN * kXLd];
@@ -161,27 +147,19 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[g][r] = 0.0f;
 
-    f32x4 qa[PLANES ? 1 : 4];
-    uint2 qp[PLANES ? 4 : 1][PL];  // the same 4 x 4 operand values as bf16 planes when the producer wrote them pre-split
+    f32x4 qa[4];
     uint4 qw[2 * PL];
     auto issue = [&](int ck) {
         const int k0 = ck * kGemmKC;
         const bool from_x = k0 < a.K1p;
         const float *src = from_x ? a.x : a.hprev;
-        const __bf16 *srcp = from_x ? a.x_p : a.hprev_p;
-        const long ldp = from_x ? a.x_ld : (long)H, plane = from_x ? a.x_plane : a.p_plane;
         const long ld = from_x ? a.ldx : (long)H;
         const int kbase = from_x ? k0 : k0 - a.K1p, kval = from_x ? a.K1 : H;
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
             const int row = min(m0 + r, a.R - 1), k = min(kbase + kq, kval - 4);  // K1, H are multiples of 4 (host-checked)
-            if constexpr (PLANES) {
-#pragma unroll
-                for (int p = 0; p < PL; p++) qp[it][p] = *reinterpret_cast<const uint2 *>(srcp + (long)p * plane + (long)row * ldp + k);
-            } else {
-                qa[it] = *reinterpret_cast<const f32x4 *>(src + (long)row * ld + k);
-            }
+            qa[it] = *reinterpret_cast<const f32x4 *>(src + (long)row * ld + k);
         }
 #pragma unroll
         for (int it = 0; it < 2 * PL; it++) {
@@ -211,22 +189,16 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
         for (int it = 0; it < 4; it++) {
             const int slot = tid + it * 256, r = slot >> 3, kq = (slot & 7) * 4;
             const bool ok = (m0 + r < a.R) && (kbase + kq < kval);  // 4-aligned windows are either all valid or all padding
-            if constexpr (PLANES) {
+            bf16x4 h, m, l;
 #pragma unroll
-                for (int p = 0; p < PL; p++) *reinterpret_cast<uint2 *>(&Ap[p][r * kXLd + kq]) = ok ? qp[it][p] : make_uint2(0, 0);
+            for (int e = 0; e < 4; e++) {
+                __bf16 hh, mm, ll;
+                split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
+                h[e] = hh; m[e] = mm; l[e] = ll;
             }
-            if constexpr (!PLANES) {
-                bf16x4 h, m, l;
-    #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    __bf16 hh, mm, ll;
-                    split3(ok ? qa[it][e] : 0.0f, hh, mm, ll);
-                    h[e] = hh; m[e] = mm; l[e] = ll;
-                }
-                *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
-                *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
-                if (PL > 2) *reinterpret_cast<bf16x4 *>(&Ap[PL - 1][r * kXLd + kq]) = l;
-            }
+            *reinterpret_cast<bf16x4 *>(&Ap[0][r * kXLd + kq]) = h;
+            *reinterpret_cast<bf16x4 *>(&Ap[1][r * kXLd + kq]) = m;
+            if (PL > 2) *reinterpret_cast<bf16x4 *>(&Ap[PL - 1][r * kXLd + kq]) = l;
         }
 #pragma unroll
         for (int it = 0; it < 2 * PL; it++) {
@@ -293,13 +265,6 @@ __global__ __launch_bounds__(256) void k_lstm_step_x6(LstmStepArgs a) {
         a.c[idx] = cn;
         a.hout[idx] = hn;
         if (a.hseq) a.hseq[(long)m * a.ldseq + j] = hn;
-        if (a.hout_p) {
-            __bf16 hh, mm, ll;
-            split3(hn, hh, mm, ll);
-            a.hout_p[idx] = hh;
-            a.hout_p[a.p_plane + idx] = mm;
-            if (PL > 2) a.hout_p[2 * a.p_plane + idx] = ll;
-        }
     }
 }
 

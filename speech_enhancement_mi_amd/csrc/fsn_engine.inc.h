@@ -14,11 +14,9 @@ struct fsn_engine {
         DevBuf Wp[4], bias[4];      // per layer: bf16x3 planes of [W_ih | W_hh] (K padded to 32s), b_ih + b_hh
         DevBuf fcw, fcw_x, fcb;
         DevBuf h[4][2], c[4];       // state
-        DevBuf hP[4][2];            // the same h as split-bf16 planes [PL][R][H] (the next step's MFMA operand, written by the cell epilogue)
         int hcur[4]{};
     } fb, sb;
     int B = 0;
-    DevBuf sbinP;  // the unfolded, normalised sub-band input as split-bf16 planes [PL][T][B*F][SI]
     DevBuf spec, maskspec, mag, fb_seq, fb_out, sbin, mask, part_fb, part_sb, mean_fb, mean_sb, denom_fb, denom_sb, yseg;
     int step_fb = 0, step_sb = 0, have_fb = 0, have_sb = 0, nslot_fb = 0, nslot_sb = 0;
     // realtime_process: the full-band model of window n + 1 runs on `side` while the sub-band model of window n runs on the caller's stream
@@ -31,10 +29,6 @@ struct fsn_engine {
     std::vector<hipEvent_t> ev_l0, ev_l1;  // per time step: layer 0 / layer 1 (+ its output layer) done
     int pipeline = 1;     // SE_FSN_PIPELINE=0: one stream, stage after stage (read at fsn_create)
     int lstm_big = 1;     // SE_FSN_BIG=0: keep the 128 x 128 step tiles where the 256-row x 64-unit tile would be picked (read at fsn_create)
-    int lstm_planes = 0;  // SE_FSN_PLANES=1: the sub-band LSTM's operands ([x_t | h_{t-1}]) as pre-split bf16 planes written by their producers
-                          // (staging = pure copy).  Measured SLOWER than splitting the fp32 operand in the K loop (B = 256: f32 8145 -> 7563,
-                          // bf16x3 11163 -> 10729 frames/s): the step is bound by the bytes its 4824 small tiles pull out of L2 (4.7 GB per
-                          // launch = 8.6 TB/s), not by the VALU split; off by default
 };
 
 namespace {
@@ -131,19 +125,9 @@ int fsn_prepare(fsn_engine *e) {
     return 0;
 }
 
-int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, long ldx, int K1, int K1p, int R, float *hseq, long ldseq, hipStream_t st,
-                  const __bf16 *xp = nullptr, long xplane = 0) {
+int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, long ldx, int K1, int K1p, int R, float *hseq, long ldseq, hipStream_t st) {
     const int hc = m.hcur[l];
     LstmStepArgs a{x, ldx, K1, K1p, m.h[l][hc].p, reinterpret_cast<const __bf16 *>(m.Wp[l].p), m.bias[l].p, m.c[l].p, m.h[l][hc ^ 1].p, hseq, ldseq, R, m.H};
-    a.hprev_p = a.x_p = nullptr; a.hout_p = nullptr; a.p_plane = (long)R * m.H; a.x_plane = 0; a.x_ld = 0;
-    // the sub-band model (R = B*F rows, 99 % of the FLOPs) runs on pre-split operand planes: h by the cell epilogue, layer 0's input by
-    // k_fsn_scale_sb; the full-band model (R = B rows) keeps the fp32 operand path
-    const bool planes = e->lstm_planes && xp != nullptr && m.hP[l][0].p && m.H % 32 == 0;
-    if (planes) {
-        a.hprev_p = reinterpret_cast<const __bf16 *>(m.hP[l][hc].p);
-        a.hout_p = reinterpret_cast<__bf16 *>(m.hP[l][hc ^ 1].p);
-        a.x_p = xp; a.x_plane = xplane; a.x_ld = ldx;
-    }
 #ifdef SE_LSTM_STAMPS
     static unsigned long long *stamps = nullptr;
     static int nlaunch = 0;
@@ -162,7 +146,7 @@ int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, lo
     }
 #endif
     // big tile (256 rows x 64 units) where it fills the chip: the sub-band model at B >= 32 streams
-    if (e->lstm_big == 1 && !planes && m.H % kLbU == 0 && R >= 32 * kLbM) {
+    if (e->lstm_big == 1 && m.H % kLbU == 0 && R >= 32 * kLbM) {
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lstm_step_big<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -178,13 +162,8 @@ int fsn_lstm_step(fsn_engine *e, fsn_engine::Model &m, int l, const float *x, lo
         return 0;
     }
     const dim3 grid((m.H + 31) / 32, (R + kGemmBM - 1) / kGemmBM);
-    if (e->c.precision == 2) {
-        if (planes) hipLaunchKernelGGL((k_lstm_step_x6<2, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_lstm_step_x6<2, false>), grid, dim3(256), 0, st, a);
-    } else {
-        if (planes) hipLaunchKernelGGL((k_lstm_step_x6<3, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_lstm_step_x6<3, false>), grid, dim3(256), 0, st, a);
-    }
+    if (e->c.precision == 2) hipLaunchKernelGGL((k_lstm_step_x6<2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_lstm_step_x6<3>), grid, dim3(256), 0, st, a);
     m.hcur[l] = hc ^ 1;
     return 0;
 }
@@ -236,23 +215,19 @@ int fsn_stage_sb(fsn_engine *e, const float *re, const float *im, long sB, long 
                            e->denom_sb.p, B, e->have_sb ? 0 : 1, alpha);
         e->have_sb = 1;
         e->step_sb = std::min(e->step_sb + 1, 80);
-        hipLaunchKernelGGL(k_fsn_scale_sb, dim3(2048), dim3(256), 0, st, e->sbin.p, B, T, F, SI, e->denom_sb.p,
-                           (e->lstm_planes && e->sbinP.p) ? reinterpret_cast<__bf16 *>(e->sbinP.p) : nullptr, e->c.precision == 2 ? 2 : 3);
+        hipLaunchKernelGGL(k_fsn_scale_sb, dim3(2048), dim3(256), 0, st, e->sbin.p, B, T, F, SI, e->denom_sb.p);
         FHIP(e, hipGetLastError());
     }
     // two layers (the reference configuration) on two streams: layer 0 of step t + 1 next to layer 1 of step t.  h of layer 0 ping-pongs
     // between two buffers: step t + 2 of layer 0 overwrites what layer 1 of step t reads, hence ev_l1[t].
-    const bool wave = consumed != nullptr && e->side2 && e->NL == 2 && (int)e->ev_l0.size() >= T && !e->lstm_planes;
+    const bool wave = consumed != nullptr && e->side2 && e->NL == 2 && (int)e->ev_l0.size() >= T;
     for (int t = 0; t < T; t++) {  // sub-band LSTM over B*F rows + Linear(H -> 2)  (fullsubnet.py:812-814)
         for (int l = 0; l < e->NL; l++) {
-            const bool pl_ok = e->lstm_planes && e->sbinP.p && SI % 32 == 0;
             hipStream_t sl = wave && l == 1 ? e->side2 : st;
             if (wave && l == 0 && t >= 2) FHIP(e, hipStreamWaitEvent(st, e->ev_l1[t - 2], 0));
             if (wave && l == 1) FHIP(e, hipStreamWaitEvent(sl, e->ev_l0[t], 0));
-            if (l == 0) fsn_lstm_step(e, e->sb, 0, e->sbin.p + (long)t * R * SI, SI, SI, (SI + 31) & ~31, R, nullptr, 0, sl,
-                                      pl_ok ? reinterpret_cast<const __bf16 *>(e->sbinP.p) + (long)t * R * SI : nullptr, (long)T * R * SI);
-            else fsn_lstm_step(e, e->sb, l, e->sb.h[l - 1][e->sb.hcur[l - 1]].p, e->sb.H, e->sb.H, (e->sb.H + 31) & ~31, R, nullptr, 0, sl,
-                               pl_ok ? reinterpret_cast<const __bf16 *>(e->sb.hP[l - 1][e->sb.hcur[l - 1]].p) : nullptr, (long)R * e->sb.H);
+            if (l == 0) fsn_lstm_step(e, e->sb, 0, e->sbin.p + (long)t * R * SI, SI, SI, (SI + 31) & ~31, R, nullptr, 0, sl);
+            else fsn_lstm_step(e, e->sb, l, e->sb.h[l - 1][e->sb.hcur[l - 1]].p, e->sb.H, e->sb.H, (e->sb.H + 31) & ~31, R, nullptr, 0, sl);
             if (wave && l == 0) FHIP(e, hipEventRecord(e->ev_l0[t], st));
         }
         const int ll = e->NL - 1;
@@ -290,7 +265,6 @@ int fsn_reset_on(fsn_engine *e, int batch, hipStream_t st) {
     if ((rc = falloc(e, e->spec, (size_t)2 * B * M * T * F * 2)) || (rc = falloc(e, e->maskspec, (size_t)B * T * F * 2)) ||
         (rc = falloc(e, e->mag, (size_t)B * T * e->Kp)) || (rc = falloc(e, e->fb_seq, (size_t)B * T * e->fb.H)) ||
         (rc = falloc(e, e->fb_out, (size_t)B * T * F)) || (rc = falloc(e, e->sbin, (size_t)T * R * e->SI)) ||
-        (e->lstm_planes && (rc = falloc(e, e->sbinP, ((size_t)3 * T * R * e->SI + 1) / 2))) ||
         (rc = falloc(e, e->mask, (size_t)R * 2 * T)) || (rc = falloc(e, e->part_fb, (size_t)B * e->nslot_fb)) ||
         (rc = falloc(e, e->part_sb, (size_t)B * e->nslot_sb)) || (rc = falloc(e, e->mean_fb, B)) || (rc = falloc(e, e->mean_sb, B)) ||
         (rc = falloc(e, e->denom_fb, B)) || (rc = falloc(e, e->denom_sb, B)))
@@ -303,14 +277,6 @@ int fsn_reset_on(fsn_engine *e, int batch, hipStream_t st) {
             FHIP(e, hipMemsetAsync(e->sb.h[l][p].p, 0, (size_t)R * e->sb.H * sizeof(float), st));
         }
         if ((rc = falloc(e, e->fb.c[l], (size_t)B * e->fb.H)) || (rc = falloc(e, e->sb.c[l], (size_t)R * e->sb.H))) return rc;
-        if (e->lstm_planes) {  // 3 bf16 planes = 1.5 floats per element (the third plane is unused in the bf16x3 mode)
-            for (int p = 0; p < 2; p++) {
-                const size_t nfb = ((size_t)3 * B * e->fb.H + 1) / 2, nsb = ((size_t)3 * R * e->sb.H + 1) / 2;
-                (void)nfb;  // (the full-band model, R = B rows, keeps the fp32 operand path)
-                if ((rc = falloc(e, e->sb.hP[l][p], nsb))) return rc;
-                FHIP(e, hipMemsetAsync(e->sb.hP[l][p].p, 0, nsb * sizeof(float), st));
-            }
-        }
         FHIP(e, hipMemsetAsync(e->fb.c[l].p, 0, (size_t)B * e->fb.H * sizeof(float), st));
         FHIP(e, hipMemsetAsync(e->sb.c[l].p, 0, (size_t)R * e->sb.H * sizeof(float), st));
         e->fb.hcur[l] = e->sb.hcur[l] = 0;
@@ -349,7 +315,6 @@ int fsn_create(const fsn_config *cfg, int device, fsn_engine **out) {
     e->SI = 2 * cfg->sb_neighbors + 2;
     e->fb.in = cfg->num_freqs * cfg->num_mics; e->fb.inp = e->Kp; e->fb.H = cfg->fb_hidden; e->fb.out = cfg->num_freqs;
     e->sb.in = e->SI; e->sb.inp = (e->SI + 31) & ~31; e->sb.H = cfg->sb_hidden; e->sb.out = 2;
-    if (const char *s = getenv("SE_FSN_PLANES")) e->lstm_planes = atoi(s);
     if (const char *s = getenv("SE_FSN_BIG")) e->lstm_big = atoi(s);
     if (const char *s = getenv("SE_FSN_PIPELINE")) e->pipeline = atoi(s);
     if (e->pipeline) {
@@ -375,13 +340,12 @@ void fsn_destroy(fsn_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (fsn_engine::Model *m : {&e->fb, &e->sb}) {
-        for (int l = 0; l < 4; l++) { dev_free(m->Wp[l]); dev_free(m->bias[l]); dev_free(m->h[l][0]); dev_free(m->h[l][1]); dev_free(m->c[l]); dev_free(m->hP[l][0]); dev_free(m->hP[l][1]); }
+        for (int l = 0; l < 4; l++) { dev_free(m->Wp[l]); dev_free(m->bias[l]); dev_free(m->h[l][0]); dev_free(m->h[l][1]); dev_free(m->c[l]); }
         dev_free(m->fcw); dev_free(m->fcw_x); dev_free(m->fcb);
     }
     for (DevBuf *b : {&e->spec, &e->maskspec, &e->mag, &e->fb_seq, &e->fb_out, &e->sbin, &e->mask, &e->part_fb, &e->part_sb, &e->mean_fb,
                       &e->mean_sb, &e->denom_fb, &e->denom_sb, &e->yseg})
         dev_free(*b);
-    dev_free(e->sbinP);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->side2) (void)hipStreamDestroy(e->side2);
     for (hipEvent_t ev : e->ev_l0) if (ev) (void)hipEventDestroy(ev);
