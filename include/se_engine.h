@@ -113,6 +113,10 @@ int se_forward(se_engine *e, const float *x, float *y, void *stream);
  * convolution [B, C, F, T], fc_output_layer output ([B, T, D] memory), transposed-convolution outputs of decoder blocks 0..L-2.
  * Synchronises the stream.  *count = elements. */
 int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream);
+/* The student's distillation feature maps "ft0".."ft<L>" (distillation_crn.py:467-477: last encoder convolution, fc layer, transposed
+ * convolutions, all before their activation) written to DEVICE memory as [B, C, F, T] fp32 on `stream`; no host copy.  Other tap names:
+ * SE_ERR_KEY (host-only debugging taps). */
+int se_read_tap_dev(se_engine *e, const char *name, float *dev_out, int64_t capacity, int64_t *count, void *stream);
 
 /* Streaming state hand-over: encoder time buffers "buf<i>" [B, Cin, F, 2d] and GRU
  * hidden "h" [layers, B, H] in the reference's layouts, HOST pointers; variants 1/2 add the preconv buffers

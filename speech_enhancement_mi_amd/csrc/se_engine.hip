@@ -1139,6 +1139,58 @@ int ensure_ready(se_engine *e) {
 
 }  // namespace
 
+namespace {
+// P layout [b][octet][plane][t][f] (16-byte pieces of 8 channels) -> fp32 [b][c][t][f]: the operands of a feature-tap re-run
+template <int PL>
+__global__ void k_tap_p_to_f32(const uint4 *P, float *dst, int B, int C, int T, int F) {
+    const int C8 = (C + 7) >> 3;
+    const long n = (long)B * C8 * T * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long tf = i % ((long)T * F), bo = i / ((long)T * F);
+        const int o = (int)(bo % C8), b = (int)(bo / C8);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int pl = 0; pl < PL; pl++) {
+            const uint4 q = P[(((long)b * C8 + o) * PL + pl) * T * F + tf];
+            if (PL == 1) {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                const h8 h = __builtin_bit_cast(h8, q);
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] += (float)h[c];
+            } else {
+                const bf16x8 h = __builtin_bit_cast(bf16x8, q);
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] += (float)h[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            if (o * 8 + c < C) dst[((long)b * C + o * 8 + c) * T * F + tf] = v[c];
+    }
+}
+// [b][c][t][f] -> [b][c][f][t] (the reference's feature-map layout, distillation_crn.py:467-477)
+__global__ void k_tap_tf_to_ft(const float *src, float *dst, long BC, int T, int F) {
+    const long n = BC * T * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const long r = i / T;
+        const int f = (int)(r % F);
+        const long bc = r / F;
+        dst[i] = src[(bc * T + t) * F + f];
+    }
+}
+int tap_p_to_f32_dev(se_engine *e, const float *psrc, int C, int F, float *dst, hipStream_t st) {
+    const int PL = operand_planes(e->precision);
+    const dim3 g(1024), b(256);
+    const uint4 *P = reinterpret_cast<const uint4 *>(psrc);
+    if (PL == 1) hipLaunchKernelGGL(k_tap_p_to_f32<1>, g, b, 0, st, P, dst, e->B, C, e->T, F);
+    else if (PL == 2) hipLaunchKernelGGL(k_tap_p_to_f32<2>, g, b, 0, st, P, dst, e->B, C, e->T, F);
+    else hipLaunchKernelGGL(k_tap_p_to_f32<3>, g, b, 0, st, P, dst, e->B, C, e->T, F);
+    HIPCHECK(e, hipGetLastError());
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int se_abi_version(void) { return 4; }
@@ -1781,8 +1833,22 @@ static int copy_out(se_engine *e, const float *dev, size_t n, float *host, int64
     return SE_OK;
 }
 
+static int read_tap_impl(se_engine *e, const char *name, float *host_out, float *dev_out, int64_t capacity, int64_t *count, void *stream);
+
 int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacity, int64_t *count, void *stream) {
     if (!e || !name || !host_out) return fail(e, SE_ERR_ARG, "null argument");
+    return read_tap_impl(e, name, host_out, nullptr, capacity, count, stream);
+}
+
+// The distillation feature maps "ft0".."ft<L>" straight into DEVICE memory ([B, C, F, T] fp32), enqueued on `stream`, no host copy and no
+// synchronisation: what a distillation training loop consumes (distillation_crn.py:467-477).  Other taps are host-only (se_read_tap).
+int se_read_tap_dev(se_engine *e, const char *name, float *dev_out, int64_t capacity, int64_t *count, void *stream) {
+    if (!e || !name || !dev_out) return fail(e, SE_ERR_ARG, "null argument");
+    if (strncmp(name, "ft", 2)) return fail(e, SE_ERR_KEY, "se_read_tap_dev serves the feature taps ft0..ft%d only (got %s)", e->L, name);
+    return read_tap_impl(e, name, nullptr, dev_out, capacity, count, stream);
+}
+
+static int read_tap_impl(se_engine *e, const char *name, float *host_out, float *dev_out, int64_t capacity, int64_t *count, void *stream) {
     if (e->B <= 0) return fail(e, SE_ERR_STATE, "no forward has run");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int L = e->L, T = e->T, B = e->B, cur = e->slot;
@@ -1844,19 +1910,21 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
         int rc = ensure_ready(e);
         if (rc) return rc;
         DevBuf tmp;
-        // On the plane path the operands of the re-run live in the P layout: they are summed back to fp32 on the host and put
-        // into the first-generation buffers the re-run reads (a tap is a training / debugging aid, not part of the hot path).
-        auto p_to_f32 = [&](const float *psrc, int C_, int F_, float *dst) -> int {
-            std::vector<float> h((size_t)B * C_ * T * F_);
-            int r = p_to_host(e, psrc, C_, F_, h.data(), st, false);
-            if (r) return r;
-            HIPCHECK(e, hipMemcpy(dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-            return 0;
-        };
+        // On the plane path the operands of the re-run live in the P layout: k_tap_p_to_f32 sums the planes back into the
+        // first-generation fp32 buffers the re-run reads (a tap is a training / debugging aid, not part of the hot path).
+        auto p_to_f32 = [&](const float *psrc, int C_, int F_, float *dst) -> int { return tap_p_to_f32_dev(e, psrc, C_, F_, dst, st); };
         auto finish = [&](int C_, int F_, bool raw_flat) -> int {
             const size_t n_ = (size_t)B * C_ * T * F_;
             if (count) *count = (int64_t)n_;
             if ((int64_t)n_ > capacity) { dev_free(tmp); return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n_); }
+            if (dev_out) {  // stays on the device: a copy (ft1: already [B, T, D] = [B, C, F, T] memory) or one transposition
+                hipError_t er;
+                if (raw_flat) er = hipMemcpyAsync(dev_out, tmp.p, n_ * sizeof(float), hipMemcpyDeviceToDevice, st);
+                else { hipLaunchKernelGGL(k_tap_tf_to_ft, dim3(1024), dim3(256), 0, st, tmp.p, dev_out, (long)B * C_, T, F_); er = hipGetLastError(); }
+                if (er == hipSuccess) er = hipStreamSynchronize(st);  // tmp is freed below (the re-run itself is the expensive part)
+                dev_free(tmp);
+                return er == hipSuccess ? SE_OK : fail(e, SE_ERR_HIP, "tap copy failed: %s", hipGetErrorString(er));
+            }
             std::vector<float> h(n_);
             hipError_t st1 = hipStreamSynchronize(st), st2 = hipMemcpy(h.data(), tmp.p, n_ * sizeof(float), hipMemcpyDeviceToHost);
             dev_free(tmp);
@@ -1906,6 +1974,7 @@ int se_read_tap(se_engine *e, const char *name, float *host_out, int64_t capacit
     const size_t n = (size_t)B * C * T * F;
     if (count) *count = (int64_t)n;
     if ((int64_t)n > capacity) return fail(e, SE_ERR_ARG, "buffer too small: need %zu floats", n);
+    if (!host_out) return fail(e, SE_ERR_KEY, "tap %s has no device form", name);
     std::vector<float> h(n);
     HIPCHECK(e, hipStreamSynchronize(st));
     HIPCHECK(e, hipMemcpy(h.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));

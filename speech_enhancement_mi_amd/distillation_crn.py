@@ -6,7 +6,8 @@ Like the reference, `forward` returns `(y, [5 feature maps])` and `realtime_proc
 [N*B, C_k, F_k, T]])` (distillation_crn.py:467-477): the pre-activation outputs of the last encoder convolution, of the
 bottleneck's fc layer and of the first three transposed convolutions, which only the distillation *training* loss consumes.
 The hot path fuses activations into the producing kernels, so the feature maps are produced by re-running those five kernels
-without activation after every segment (engine taps "ft0".."ft4") and cross the host: set `return_features = False` for
+without activation after every segment (engine taps "ft0".."ft4", written to device memory by `se_read_tap_dev`; they never cross the
+host): set `return_features = False` for
 inference (`predict_distillation.py:84` discards them) to get `(pred, None)` at full streaming speed."""
 import torch
 
@@ -17,23 +18,22 @@ class TemporalCRN(_Base):
     _VARIANT = 2
     return_features = True
 
-    def _features(self, eng, B):
-        L = len(self._cfg_args["num_channels"])
-        T = eng.T
-        out = []
-        for k in range(L + 1):
-            a = eng.read_tap(f"ft{k}")
-            out.append(torch.from_numpy(a.reshape(B, -1, T)))  # [B, C*F, T]; reshaped to [B, C, F, T] by the caller
-        return out
-
-    def _shape_features(self, feats, B):
+    def _feature_shapes(self):
         c = self._cfg_args["num_channels"]
         L = len(c)
         F = [self.num_freqs]
         for _ in range(L):
             F.append((F[-1] - 1) // 2 + 1)
-        shapes = [(c[-1], F[L]), (c[-1], F[L])] + [(c[L - 2 - j], 2 * F[L - j] - 1) for j in range(L - 1)]
-        return [f.reshape(f.shape[0], ch, fr, -1) for f, (ch, fr) in zip(feats, shapes)]
+        return [(c[-1], F[L]), (c[-1], F[L])] + [(c[L - 2 - j], 2 * F[L - j] - 1) for j in range(L - 1)]
+
+    def _features(self, eng, B):
+        """The five taps of the segment just processed as DEVICE tensors [B, C*F, T] (se_read_tap_dev: the re-run kernels write
+        device memory; nothing crosses the host)."""
+        T = eng.T
+        return [eng.read_tap_dev(f"ft{k}", B * ch * fr * T).view(B, ch * fr, T) for k, (ch, fr) in enumerate(self._feature_shapes())]
+
+    def _shape_features(self, feats, B):
+        return [f.reshape(f.shape[0], ch, fr, -1) for f, (ch, fr) in zip(feats, self._feature_shapes())]
 
     def forward(self, x):
         y = super().forward(x)

@@ -18,7 +18,7 @@ SE_MAX_LEVELS = 8
 
 EXPORTS = [
     "se_abi_version", "se_config_size", "fsn_config_size", "se_create", "se_destroy", "se_last_error", "se_load_param", "se_reset", "se_reset_stream", "se_step",
-    "se_realtime_process", "se_realtime_process_ragged", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_export_state",
+    "se_realtime_process", "se_realtime_process_ragged", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_read_tap_dev", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
     "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
@@ -83,6 +83,7 @@ def load_library():
     L.se_istft.argtypes = [vp, fp, C.c_int, fp, vp]
     L.se_forward.argtypes = [vp, fp, fp, vp]
     L.se_read_tap.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
+    L.se_read_tap_dev.argtypes = [vp, C.c_char_p, vp, C.c_int64, i64p, vp]
     L.se_export_state.argtypes = [vp, C.c_char_p, fp, C.c_int64, i64p, vp]
     L.se_import_state.argtypes = [vp, C.c_char_p, fp, C.c_int64, vp]
     L.se_flops_per_frame.argtypes = [vp]
@@ -293,6 +294,16 @@ class Engine:
 
     def read_tap(self, name: str) -> np.ndarray:
         return self._host_read(self.lib.se_read_tap, name)
+
+    def read_tap_dev(self, name: str, numel: int):
+        """A distillation feature tap ("ft0".."ft<L>") as a flat fp32 DEVICE tensor of `numel` elements ([B, C, F, T] memory): no host copy."""
+        import torch
+        out = torch.empty(int(numel), dtype=torch.float32, device=f"cuda:{self.device}")
+        n = C.c_int64(0)
+        self._check(self.lib.se_read_tap_dev(self._h, name.encode(), C.c_void_p(out.data_ptr()), int(numel), C.byref(n), self._stream()))
+        if n.value != numel:
+            raise RuntimeError(f"tap {name}: engine wrote {n.value} elements, caller expected {numel}")
+        return out
 
     def export_state(self, name: str) -> np.ndarray:
         return self._host_read(self.lib.se_export_state, name)

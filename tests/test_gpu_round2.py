@@ -77,6 +77,7 @@ def test_student_feature_taps_golden(vgolden):
     y, feats = m.realtime_process(_cuda(mix[..., :8000]))
     assert rel_rms(y.cpu().numpy(), vgolden["student_tiny_out"]) < TOL
     assert len(feats) == 5 == len(m.get_channel_num())
+    assert all(f.is_cuda for f in feats)  # se_read_tap_dev: the feature maps never cross the host
     for i, (f, ch) in enumerate(zip(feats, m.get_channel_num())):
         ref = vgolden[f"student_tiny_feat{i}"]
         assert f.shape[1] == ch and tuple(f.shape[1:]) == ref.shape[1:], (i, f.shape, ref.shape)

@@ -486,6 +486,23 @@ def test_fsn_window_pipeline_is_bit_identical_to_one_stream(monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("precision", [0, 2, 1])
+def test_student_feature_taps_device_form_equals_host_form(precision):
+    """se_read_tap_dev("ft<k>") (planes summed back by k_tap_p_to_f32, the re-run, one device transposition) writes exactly what the
+    host tap returns, at the full student geometry and in every operand format (3 / 2 bf16 planes, one fp16 plane)."""
+    e = _engine(STUDENT400, 2, precision=precision, seed=1)
+    mix, _ = synth.synth_utterances(3, 6400, 3, seed=31)
+    e.reset(3)
+    for n in range(2):
+        e.step(_cuda(mix[:, :, n * 1600:n * 1600 + 3200]))
+    for k in range(5):
+        host = e.read_tap(f"ft{k}")
+        dev = e.read_tap_dev(f"ft{k}", host.size)
+        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), host), k
+    with pytest.raises(RuntimeError):
+        e.read_tap_dev("enc0", 16)
+
+
 # ---- config 5 in its named dtype at size; the bounded regression guard of the round-2 fault -------------------------------------
 def test_student_batch1024_fp16_named_dtype():
     """BASELINE configs[4] names fp16: precision = 1 (fp16 MFMA operands, fp32 accumulation and storage of the recurrence / norms) at
