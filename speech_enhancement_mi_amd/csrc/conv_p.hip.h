@@ -138,16 +138,40 @@ __global__ __launch_bounds__(256, NT <= 6 ? 2 : 1) void k_conv_p(ConvPArgs a) {
     const int NI = (items + 255) >> 8;
     unsigned voff[kPNiMax];  // byte offset of chunk 0's source piece, or kPOob for the zero halo
     {
+        // item it = tid + 256 k = (q * R + r) * St + slot: the patch row index rr = q * R + r and the slot advance by (256 / St, 256 % St)
+        // per k with one carry, q = rr / R is the only division left per item, and every offset is 32-bit (24-bit multiplies).
+        // (The prologue up to the first staging costs 8-15 k cycles per workgroup, 12 % of all conv_p cycles, and it is NOT this
+        // arithmetic: the first version - three reciprocal-multiply divisions and 64-bit indices per item - and this one trace the same
+        // (profiles/r03_convp_phase_trace_{serial,incremental_plan}.txt); a host-built offset table traced 1.5-2x worse, its 72 KB of loads
+        // per workgroup arriving when every workgroup of the launch starts at once (..._after.txt).)
+        const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
+        const float invR = 1.0f / (float)R, invSt = 1.0f / (float)St, invRTp = 1.0f / (float)RTp;
         const long sb = (long)b * a.C8 * PL * a.T * a.Fi;
         const unsigned base_cur = (unsigned)((a.cur_off + sb) * 16), base_prev = (unsigned)((a.prev_off + sb) * 16);
-        const unsigned *pt = a.plan + (long)blockIdx.x * (kPNiMax * 256) + tid;
+        const bool has_prev = a.prev_off >= 0;
+        const int d_r = (int)((256.0f + 0.5f) * invSt), d_slot = 256 - d_r * St;  // uniform
+        int rr = (int)(((float)tid + 0.5f) * invSt), slot = tid - rr * St;
+        const int rows = PL * CO * R;
 #pragma unroll
         for (int k = 0; k < kPNiMax; k++) {
             voff[k] = kPOob;
             if (k < NI) {
-                const unsigned t = pt[k * 256];
-                const bool hist = (t >> 31) != 0;
-                if (t != kPOob && !(hist && a.prev_off < 0)) voff[k] = (hist ? base_prev : base_cur) + (t & 0x7FFFFFFFu);
+                if (rr < rows) {  // it < items
+                    const int q = (int)(((float)rr + 0.5f) * invR), r = rr - q * R;  // q = pl * CO + oc
+                    const int pl = q / CO, oc = q - pl * CO;
+                    const int col = a.deint ? (slot < a.Sh ? 2 * slot : 2 * (slot - a.Sh) + 1) : slot;  // even columns first, then the odd ones
+                    const int g = NGp > 1 ? (int)(((float)r + 0.5f) * invRTp) : 0, j = r - g * RTp;
+                    const int ts = ta + a.tlo_off + g * a.dil + j;
+                    const int fi = col - a.colpad;
+                    const bool hist = ts < 0;
+                    const bool ok = fi >= 0 && fi < a.Fi && (hist ? (has_prev && ts + a.T >= 0) : ts < a.T);
+                    if (ok) {
+                        const unsigned row = __umul24((unsigned)(oc * PL + pl), (unsigned)a.T) + (unsigned)(hist ? ts + a.T : ts);
+                        voff[k] = (hist ? base_prev : base_cur) + ((__umul24(row, (unsigned)a.Fi) + (unsigned)fi) << 4);
+                    }
+                }
+                slot += d_slot; rr += d_r;
+                if (slot >= St) { slot -= St; rr++; }
             }
         }
     }

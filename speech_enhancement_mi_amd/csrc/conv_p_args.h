@@ -21,11 +21,6 @@ struct ConvPArgs {
     int s, colpad, tlo_off, ngroup, dil, grouped, ntap;
     int rowgrp[kMaxTaps], coloff[kMaxTaps];
     int nchunk, tiles_per_wg, St;
-    // LDS-DMA plan [workgroups per stream][kPNiMax][256]: entry (k, tid) of workgroup x = the source of LDS slot tid + 256 k of chunk 0, as a byte
-    // offset relative to (ring slot base + stream base), bit 31 = the row lies in the HISTORY slot, kPOob = zero halo.  Built on the host
-    // per (layer, tiling) (convp_engine.inc.h:build_dma_plan): in the kernel the same table cost 8-14 k cycles per workgroup (three
-    // reciprocal-multiply divisions, two integer multiplies and 64-bit adds per item, 18 items per lane) - 12 % of all conv_p cycles
-    const unsigned *plan;
     unsigned long long *trace;  // -DSE_CP_TRACE builds: 8 cycle sums per launch site (nullptr otherwise; never read by the kernel)
     int deint, Sh;          // deint = 1 (stride-2 convolutions): an LDS patch row holds its even columns first, then its odd ones (Sh = (St+1)/2
                             // even slots): column 2m + coloff of lane m becomes slot m + const, a unit-stride ds_read_b128 walk (coloff[] is

@@ -18,8 +18,7 @@ struct ConvPPlan {
     int NT = 0, CO = 1, grid_x = 0;
     size_t lds = 0;
     bool active = false;
-    DevBuf wx, bias, plan;
-    int plan_nt = -1, plan_pl = 0;  // tiling / operand planes the DMA plan table was built for
+    DevBuf wx, bias;
     double flops = 0;
     struct Geo { int NT = 0, tpw = 0, n_wg = 0, grouped = 0; size_t lds = 0; long items = 0; } geo[16];
     int ngeo = 0;
@@ -161,46 +160,6 @@ int plan_conv_p(se_engine *e, ConvPPlan &pl, int Ci, int Co, int FP, int Fi, int
     return 0;
 }
 
-// The LDS-DMA plan of k_conv_p for the chosen tiling (ConvPArgs::plan): the index arithmetic the kernel used to do per lane, once per (layer, tiling).
-// Mirrors k_conv_p's geometry: p0 / p1 -> rows ta..tb, R patch rows of St slots, item = (plane * CO + octet) * Npos + patch position.
-int build_dma_plan(se_engine *e, ConvPPlan &pl) {
-    const ConvPArgs &a = pl.a;
-    const int PL = operand_planes(e->precision), CO = pl.CO;
-    if (pl.plan.p && pl.plan_nt == pl.NT && pl.plan_pl == PL) { pl.a.plan = reinterpret_cast<const unsigned *>(pl.plan.p); return 0; }
-    std::vector<unsigned> tab((size_t)pl.grid_x * kPNiMax * 256, kPOob);
-    const int P = a.T * a.FP;
-    for (int x = 0; x < pl.grid_x; x++) {
-        const int p0 = x * a.tiles_per_wg * 32;
-        if (p0 >= P) continue;
-        const int p1 = std::min(P, p0 + a.tiles_per_wg * 32);
-        const int ta = p0 / a.FP, tb = (p1 - 1) / a.FP, RT = tb - ta + 1;
-        const int R = a.grouped ? a.ngroup * RT : RT + (a.ngroup - 1) * a.dil;
-        const int St = a.St, Npos = R * St;
-        const long items = (long)PL * CO * Npos;
-        const int NGp = a.grouped ? a.ngroup : 1, RTp = a.grouped ? RT : R;
-        for (long it = 0; it < items && it < 256L * kPNiMax; it++) {
-            const int q = (int)(it / Npos), pe = (int)(it - (long)q * Npos);
-            const int pln = q / CO, oc = q - pln * CO;
-            const int r = pe / St, slot = pe - r * St;
-            const int col = a.deint ? (slot < a.Sh ? 2 * slot : 2 * (slot - a.Sh) + 1) : slot;
-            const int g = NGp > 1 ? r / RTp : 0, j = r - g * RTp;
-            const int ts = ta + a.tlo_off + g * a.dil + j;
-            const int fi = col - a.colpad;
-            const bool hist = ts < 0;
-            const bool ok = fi >= 0 && fi < a.Fi && (hist ? ts + a.T >= 0 : ts < a.T);
-            if (!ok) continue;
-            const long rel = (((long)(oc * PL + pln) * a.T + (hist ? ts + a.T : ts)) * a.Fi + fi) * 16;
-            tab[((size_t)x * kPNiMax + (size_t)(it >> 8)) * 256 + (it & 255)] = (unsigned)rel | (hist ? 0x80000000u : 0u);
-        }
-    }
-    int rc = dev_alloc(e, pl.plan, (tab.size() + 0) * sizeof(unsigned) / sizeof(float));
-    if (rc) return rc;
-    HIPCHECK(e, hipMemcpy(pl.plan.p, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    pl.plan_nt = pl.NT; pl.plan_pl = PL;
-    pl.a.plan = reinterpret_cast<const unsigned *>(pl.plan.p);
-    return 0;
-}
-
 // Picks the tiling for the current batch: time ~ rounds x (workgroups per CU x MFMA cycles + staging + epilogue)
 void select_convp_geometry(se_engine *e, ConvPPlan &pl) {
     if (!pl.active) return;
@@ -229,7 +188,6 @@ void select_convp_geometry(se_engine *e, ConvPPlan &pl) {
     const ConvPPlan::Geo &g = pl.geo[pick];
     pl.NT = g.NT; pl.grid_x = g.n_wg; pl.lds = g.lds;
     pl.a.tiles_per_wg = g.tpw; pl.a.grouped = g.grouped;
-    build_dma_plan(e, pl);
 }
 
 #ifdef SE_CP_TRACE
@@ -285,12 +243,12 @@ void free_state_p(se_engine *e) {
     if (!e->cp) return;
     se_convp_state &S = *e->cp;
     for (int i = 0; i < SE_MAX_LEVELS; i++) {
-        for (ConvPPlan *p : {&S.pv[i].enc, &S.pv[i].dec_even, &S.pv[i].dec_odd, &S.pv[i].skip, &S.pv[i].skipm, &S.pv[i].gate[0], &S.pv[i].gate[1]}) { dev_free(p->wx); dev_free(p->bias); dev_free(p->plan); }
+        for (ConvPPlan *p : {&S.pv[i].enc, &S.pv[i].dec_even, &S.pv[i].dec_odd, &S.pv[i].skip, &S.pv[i].skipm, &S.pv[i].gate[0], &S.pv[i].gate[1]}) { dev_free(p->wx); dev_free(p->bias); }
         dev_free(S.pv[i].sk.wx); dev_free(S.pv[i].sk.cst);
         dev_free(S.xinP[i]); dev_free(S.encR[i]); dev_free(S.encA[i]); dev_free(S.decR[i]); dev_free(S.decP[i]);
     }
     for (int r = 0; r < kRing; r++) dev_free(S.decinP[r]);
-    for (int i = 0; i < 3; i++) { dev_free(S.pre[i].wx); dev_free(S.pre[i].bias); dev_free(S.pre[i].plan); dev_free(S.pinP[i]); dev_free(S.pre_gw[i]); }
+    for (int i = 0; i < 3; i++) { dev_free(S.pre[i].wx); dev_free(S.pre[i].bias); dev_free(S.pinP[i]); dev_free(S.pre_gw[i]); }
     dev_free(S.preR);
     delete e->cp;
     e->cp = nullptr;
