@@ -33,6 +33,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  One leg uses the caller's stream + three
+# stage streams (CRN), or + two side streams (FullSubNet / training layer wavefront) + the loss graph's stream: with earlier legs' streams in
+# the round-robin, two of a leg's own streams can land on one queue and serialise (training leg 289 -> 306 utt/s, student +1 %, CRN_ELU
+# +2 % with 8 queues; the headline itself is unchanged).  Read by the runtime at initialisation, inherited by the rank processes.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 dense peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (spec)
 
@@ -383,8 +389,11 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
     if args.train_kernels == "hip":  # one extra profiled step: events around every hand-written launch on the launch stream
         from speech_enhancement_mi_amd import train_ops
         train_ops.PROF = {}
-        step()
-        prof = train_ops.profile_summary()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.Stream()):  # timed events taint their queue (see measure_crn): keep the default stream clean
+            step()
+            prof = train_ops.profile_summary()
+        torch.cuda.synchronize()
         train_ops.PROF = None
         bwd = {k: v for k, v in prof.items() if v["flops"] > 0}
         dom = max(bwd, key=lambda k: bwd[k]["ms"])
@@ -507,10 +516,17 @@ def measure_crn(model, nfft, B, dtype, seconds, steps, warmup, rank, local_rank,
     progress(f"{label_progress}{value:.0f} frames/s; profiled step")
 
     # ---- roofline leg: one extra profiled step, HIP events around every launch on the launch stream ----
-    eng.profile(True)
-    eng.realtime_process(mix, out=out)
-    recs = eng.profile_read()
-    eng.profile(False)
+    # On a stream of its own: timed events switch the stream's HSA queue to profiling mode for good, and everything launched on that
+    # queue afterwards pays for it - the launch-dense secondary legs ran 14-16 % slower on the tainted default stream (FullSubNet 10.4 k
+    # -> 9.0 k frames/s, training 335 -> 282 utt/s; profiles/leg_order_probe.py).  (Moving the LEGS to fresh streams instead costs the
+    # pipelined CRN legs 5-13 %: a fifth stream next to the engine's three stage streams shares one of the four hardware queues.)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        eng.profile(True)
+        eng.realtime_process(mix, out=out)
+        recs = eng.profile_read()
+        eng.profile(False)
+    torch.cuda.synchronize()
     by_kernel = {}
     for r in recs:
         k = by_kernel.setdefault(r["kernel"], dict(ms=0.0, launches=0, flops=0.0))
