@@ -225,7 +225,9 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     merge=False runs the micro-batches one after the other like the reference loop.
 
     graph_loss (default: on with the hand-written kernels): the full loss (STOI + SI-SNR, ~150 small launches) runs as a captured HIP
-    graph per (micro-batch shape), forward and backward (losses.compute_loss_graphed); values and gradient unchanged."""
+    graph per (micro-batch shape), forward and backward (losses.compute_loss_graphed); values and gradient unchanged.  A new shape costs
+    one capture (~1 s) and the 16 most recent shapes are kept: a trainer whose padded length changes every step should bucket its
+    lengths or pass graph_loss=False."""
     bucket.zero()
     total = 0.0
     if merge is None:
