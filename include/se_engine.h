@@ -93,9 +93,12 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
 
 /* Ragged batch (the reference's utterances are 1 .. 3.75 s long, data_c.py:155-173): stream b holds lengths[b] <= max_length valid
  * samples of mixture [B, M, max_length]; every stream gets exactly the output it would get alone - its own zero padding (samples past
- * its length read as zeros) and out[b, lengths[b]:] = 0.  lengths is a HOST array.  The batch still runs max-length segments: a stream
- * that has ended keeps its slot busy until the call ends (no compaction), and its carried state has then also seen those zero segments:
- * follow with flag = 0, or se_reset_stream, for streams that ended early. */
+ * its length read as zeros) and out[b, lengths[b]:] = 0.  lengths is a HOST array.
+ * Prefix compaction: when the lengths are NON-INCREASING (sort the batch; the Python shim does) every segment is launched for the prefix
+ * of streams that still take part in it only - every layout is stream-major, so nothing moves; grids, GEMM rows and recurrence rows
+ * shrink (plane path, CRN.py variant, batches on the plane-GEMM route; SE_RAGGED_COMPACT=0 turns it off).  With unsorted lengths every
+ * stream runs every segment.  Either way the carried state of a stream that ended early is not a continuation state: follow with
+ * flag = 0, or se_reset_stream, for those streams. */
 int se_realtime_process_ragged(se_engine *e, const float *mixture, int batch, int64_t max_length, const int64_t *lengths_host, int flag, float *out,
                                void *stream);
 

@@ -223,7 +223,7 @@ int launch_conv_p(se_engine *e, const ConvPPlan &pl, const ConvPArgs &a_in, hipS
 #ifdef SE_CP_TRACE
     a.trace = g_cp_trace_sites.get(label, pl.NT, pl.grid_x);
 #endif
-    if (conv_p_launch(a.ntap, pl.NT, pl.CO, operand_planes(e->precision), dim3(pl.grid_x, e->B), pl.lds, st, a))
+    if (conv_p_launch(a.ntap, pl.NT, pl.CO, operand_planes(e->precision), dim3(pl.grid_x, e->Bact), pl.lds, st, a))
         return fail(e, SE_ERR_ARG, "no conv_p kernel instance for %d taps x %d tiles x %d octets", a.ntap, pl.NT, pl.CO);
     HIPCHECK(e, hipGetLastError());
     return 0;
@@ -512,13 +512,14 @@ int alloc_state_p(se_engine *e, hipStream_t st) {
 int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, long sM, long sT, long sF, hipStream_t st) {
     se_convp_state &S = *e->cp;
     const int L = e->L, T = e->T, B = e->B, PL = operand_planes(e->precision);
+    const int Ba = e->Bact;  // launch batch: the prefix of streams that take part in this segment (se_realtime_process_ragged), B otherwise
     int rc;
     if (e->variant && S.pre_p) {  // features and the three pre-conv blocks x = m(x) + x on the plane path
         const int TF = T * e->F[0], C0 = e->Ch[0];
         {
             ProfScope ps(e, "k_featurize_p", "featurize", 0, st);
             FeatPArgs f{spec, sB, sM, sT, sF, reinterpret_cast<uint4 *>(S.pinP[0].p) + (long)cur * S.pslot_elems, (long)PL * TF, e->M, T, e->F[0], e->atan2_phase};
-            launch_k_featurize_p(PL, dim3((TF + 255) / 256, B), st, f);
+            launch_k_featurize_p(PL, dim3((TF + 255) / 256, Ba), st, f);
             HIPCHECK(e, hipGetLastError());
         }
         for (int i = 0; i < e->npre; i++) {
@@ -541,7 +542,7 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
             g.y = i + 1 < e->npre ? reinterpret_cast<uint4 *>(S.pinP[i + 1].p) + (long)cur * S.pslot_elems
                                   : reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0];
             g.y_stream = (long)PL * TF;
-            launch_k_gln_p(PL, dim3((TF + 1023) / 1024, 1, B), st, g);
+            launch_k_gln_p(PL, dim3((TF + 1023) / 1024, 1, Ba), st, g);
             HIPCHECK(e, hipGetLastError());
         }
     } else if (e->variant) {  // the same blocks on their fp32 vector-ALU kernel (first generation), then one conversion into the P layout
@@ -549,13 +550,13 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
         ProfScope ps(e, "k_f32_to_p", "feat_to_p", 0, st);
         const int TF = T * e->F[0];
         F32ToPArgs f{e->xin[0][cur].p, reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0], (long)PL * TF, e->Ch[0], TF};
-        launch_k_f32_to_p(PL, dim3((TF + 255) / 256, B), st, f);
+        launch_k_f32_to_p(PL, dim3((TF + 255) / 256, Ba), st, f);
         HIPCHECK(e, hipGetLastError());
     } else {
         ProfScope ps(e, "k_featurize_p", "featurize", 0, st);
         const int TF = T * e->F[0];
         FeatPArgs f{spec, sB, sM, sT, sF, reinterpret_cast<uint4 *>(S.xinP[0].p) + (long)cur * S.slot_elems[0], (long)PL * TF, e->M, T, e->F[0], e->atan2_phase};
-        launch_k_featurize_p(PL, dim3((TF + 255) / 256, B), st, f);
+        launch_k_featurize_p(PL, dim3((TF + 255) / 256, Ba), st, f);
         HIPCHECK(e, hipGetLastError());
     }
     for (int i = 0; i < L; i++) {
@@ -597,12 +598,12 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
             g.mode = 0;
             g.y = reinterpret_cast<uint4 *>(S.xinP[i + 1].p) + (long)cur * S.slot_elems[i + 1];
             g.y_stream = (long)g.C8 * PL * T * Fo;
-            launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, B), st, g);
+            launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, Ba), st, g);
         } else if (e->gemm_p) {  // last level = A operand of the GRU input projection, as split-bf16 planes (k_gemm_p)
             g.mode = 1;
             g.y = reinterpret_cast<uint4 *>(e->gruinP[cur].p);
             g.y_plane = (long)B * T * g.C8 * Fo;
-            launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, B), st, g);
+            launch_k_gln_p(PL, dim3((T * Fo + 1023) / 1024, g.C8, Ba), st, g);
         } else {  // last level feeds the fp32 GEMM of the bottleneck: [T][C*F] rows (gln_ew mode 1 of the first generation)
             GlnEwArgs ge{nullptr, e->gru_in[cur].p, g.w, g.b, g.st, 3, Co, T, Fo, nullptr};
             ge.x = S.encR[i].p;
@@ -618,6 +619,7 @@ int stage_encoder_p(se_engine *e, int cur, int prev, const cf2 *spec, long sB, l
 int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, long sF, cf2 *out, long oB, long oT, long oF, hipStream_t st) {
     se_convp_state &S = *e->cp;
     const int L = e->L, T = e->T, B = e->B, PL = operand_planes(e->precision);
+    const int Ba = e->Bact;  // launch batch: the prefix of streams that take part in this segment (se_realtime_process_ragged), B otherwise
     int rc;
     const uint4 *xin = reinterpret_cast<const uint4 *>(S.decinP[cur].p);
     size_t xin_bytes = (size_t)B * ((e->Ch[L] + 7) / 8) * PL * T * e->F[L] * 16;
@@ -649,7 +651,7 @@ int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, lo
                 a.sy = sy;
                 a.out = reinterpret_cast<uint4 *>(S.decP[j].p);
                 ProfScope ps(e, "k_skip_p", ("skip" + std::to_string(j)).c_str(), pv.sk.flops * B, st);
-                if (launch_k_skip_p(PL, pv.sk.KP, B, pv.sk.lds, st, a)) return fail(e, SE_ERR_ARG, "no k_skip_p instance for %d planes x %d K steps", PL, pv.sk.KP);
+                if (launch_k_skip_p(PL, pv.sk.KP, Ba, pv.sk.lds, st, a)) return fail(e, SE_ERR_ARG, "no k_skip_p instance for %d planes x %d K steps", PL, pv.sk.KP);
                 HIPCHECK(e, hipGetLastError());
             } else {
             {
@@ -676,7 +678,7 @@ int stage_decoder_p(se_engine *e, int cur, const cf2 *spec, long sB, long sT, lo
             if (Fo != e->F[0]) return fail(e, SE_ERR_ARG, "decoder output has %d bins, spectrum has %d", Fo, e->F[0]);
             MaskPArgs m{S.decR[j].p, (long)T * Fi * 8, Fi, e->lv[j].dec_nw.p, e->lv[j].dec_nb.p, sy, spec, sB, sT, sF, out, oB, oT, oF, T, e->F[0]};
             ProfScope ps(e, "k_final_mask_p", "final_mask", 0, st);
-            launch_k_final_mask_p(dim3((T * e->F[0] + 1023) / 1024, B), st, m);
+            launch_k_final_mask_p(dim3((T * e->F[0] + 1023) / 1024, Ba), st, m);
             HIPCHECK(e, hipGetLastError());
         }
     }

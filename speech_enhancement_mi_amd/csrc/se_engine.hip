@@ -136,6 +136,12 @@ struct se_engine {
     DevBuf yseg;
     DevBuf ragged_len;       // se_realtime_process_ragged: per-stream lengths (int64) on the device
     bool ragged_on = false;
+    // Prefix compaction of a ragged batch: every layout is stream-major, so when the lengths are non-increasing the streams that still take
+    // part in segment n are a PREFIX of the batch and every launch of that segment simply covers Bact < B streams (grids, GEMM rows, GRU
+    // rows); strides and plane sizes stay those of the allocation batch B.  Bact is set per stage call by se_realtime_process.
+    int Bact = 0;
+    int bact_slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launch batch of the segment living in each ring slot (the lagged GRU rounds mix segments)
+    std::vector<int> ragged_nseg;  // per stream: segments it takes part in (empty: all)
     // second-generation convolution path (conv_p.hip.h): activations as split-bf16 planes; SE_PATH=0 selects the first generation
     struct se_convp_state *cp = nullptr;
     int path = 1;
@@ -759,8 +765,10 @@ int launch_gemm_p(se_engine *e, const float *Ap, const float *Wp, const float *b
         gx = -1; gy = per;
         nblocks = 8 * per;
     }
-    GemmPArgs g{reinterpret_cast<const uint4 *>(Ap), reinterpret_cast<const uint4 *>(Wp), (long)Mr * Kd / 8, (long)Nc * Kd / 8, bias, C, Mr, Nc, Kd, ldc, relu,
-                (unsigned)((size_t)PL * Mr * Kd * 2), (unsigned)((size_t)PL * Nc * Kd * 2), nrt, nct, gx, gy};
+    // the A planes are laid out for the ALLOCATION batch ([PL][B * T][K]); a ragged call multiplies a prefix of the rows only (Mr = Bact * T)
+    const long Ma = std::max<long>(Mr, (long)e->B * e->T);
+    GemmPArgs g{reinterpret_cast<const uint4 *>(Ap), reinterpret_cast<const uint4 *>(Wp), Ma * Kd / 8, (long)Nc * Kd / 8, bias, C, Mr, Nc, Kd, ldc, relu,
+                (unsigned)((size_t)PL * Ma * Kd * 2), (unsigned)((size_t)PL * Nc * Kd * 2), nrt, nct, gx, gy};
     const dim3 grid(nblocks);
     const size_t lds = (size_t)2 * 1536 * PL * 16;
     if (PL == 1) hipLaunchKernelGGL(k_gemm_p<1>, grid, dim3(512), lds, st, g);
@@ -872,18 +880,21 @@ uint4 *decin_p(se_engine *e, int slot);  // convp_engine.inc.h: decoder-input ri
 int stage_gru_proj0(se_engine *e, int cur, hipStream_t st) {
     const int T = e->T, B = e->B, H = e->H, D = e->D;
     if (e->dbg_skip & 2) return 0;
-    if (e->gemm_p) return launch_gemm_p(e, e->gruinP[cur].p, e->wih_xp.p, e->bih[0].p, e->gi0[cur].p, 3L * H, B * T, 3 * H, D, 0, st, "gru_ih0");
-    return launch_gemm(e, e->gru_in[cur].p, D, e->wih[0].p, D, e->bih[0].p, e->gi0[cur].p, 3L * H, B * T, 3 * H, D, 0, st, "gru_ih0", e->wih_x[0].p);
+    const int Ba = e->Bact;
+    (void)B;
+    if (e->gemm_p) return launch_gemm_p(e, e->gruinP[cur].p, e->wih_xp.p, e->bih[0].p, e->gi0[cur].p, 3L * H, Ba * T, 3 * H, D, 0, st, "gru_ih0");
+    return launch_gemm(e, e->gru_in[cur].p, D, e->wih[0].p, D, e->bih[0].p, e->gi0[cur].p, 3L * H, Ba * T, 3 * H, D, 0, st, "gru_ih0", e->wih_x[0].p);
 }
 
 int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlapped) {
     const int T = e->T, B = e->B, H = e->H;
+    const int Ba = e->Bact;  // rows that take part (prefix of the batch)
     int rc;
     const float *gi = e->gi0[cur].p;
     if (l > 0) {
         gi = e->gil[l].p;
         if (e->dbg_skip & 2) {}
-        else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][cur].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
+        else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][cur].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, Ba * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
         else if ((rc = launch_gemm(e, e->seqr[l - 1][cur].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
                                    ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
     }
@@ -909,13 +920,13 @@ int stage_gru_layer(se_engine *e, int l, int cur, hipStream_t st, bool overlappe
     for (int t = 0; t < T && !(e->dbg_skip & 1); t++) {
         const int hc = e->hcur[l];
         GruStepArgs g{gi + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
-                      e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, B, H};
+                      e->hbuf[l][hc ^ 1].p, seq + (long)t * H, (long)T * H, Ba, H};
         if (e->gemm_p) {
             g.seqp = reinterpret_cast<__bf16 *>(e->seqP[l][cur].p) + (long)t * H;
             g.seqp_ld = (long)T * H; g.seqp_plane = (long)B * T * H; g.seqp_pl = operand_planes(e->precision);
         }
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H, st);
-        const dim3 grid((H + 15) / 16, (B + 31) / 32);
+        const dim3 grid((H + 15) / 16, (Ba + 31) / 32);
         // (<= 16 streams: the register-streaming kernel splits K over all four waves and beats the LDS-slice kernel: 9.3 vs 10.4 us)
         const bool direct = e->gru_direct >= 0 ? e->gru_direct != 0 : (overlapped || B <= 16);
         if (H == 512 && !direct) hipLaunchKernelGGL(k_gru_step2<16>, grid, dim3(256), (size_t)192 * H, st, g);
@@ -943,12 +954,15 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
         if (l > 0) {
             gi[l] = e->gil[l].p;
             if (e->dbg_skip & 2) {}
-            else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][slots[l]].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
+            else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[l - 1][slots[l]].p, e->wih_x[l].p, e->bih[l].p, e->gil[l].p, 3L * H, e->bact_slot[slots[l]] * T, 3 * H, H, 0, st, ("gru_ih" + std::to_string(l)).c_str()))) return rc; }
             else if ((rc = launch_gemm(e, e->seqr[l - 1][slots[l]].p, H, e->wih[l].p, H, e->bih[l].p, e->gil[l].p, 3L * H, B * T, 3 * H, H, 0, st,
                                        ("gru_ih" + std::to_string(l)).c_str(), e->wih_x[l].p))) return rc;
         }
     }
     if (!nact) return 0;
+    int bmax = 0;  // every layer's own row count is in its arguments; the grid covers the largest
+    for (int l = 0; l < e->NL; l++)
+        if (slots[l] >= 0) bmax = std::max(bmax, e->bact_slot[slots[l]]);
     for (int t = 0; t < T && !(e->dbg_skip & 1); t++) {
         GruStepMulti m{};
         int z = 0;
@@ -957,7 +971,7 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
             const int hc = e->hcur[l];
             GruStepArgs &ga = m.a[z++];
             ga = GruStepArgs{gi[l] + (long)t * 3 * H, (long)T * 3 * H, e->hbuf[l][hc].p, e->whh[l].p, e->bhh[l].p,
-                             e->hbuf[l][hc ^ 1].p, e->seqr[l][slots[l]].p + (long)t * H, (long)T * H, B, H};
+                             e->hbuf[l][hc ^ 1].p, e->seqr[l][slots[l]].p + (long)t * H, (long)T * H, e->bact_slot[slots[l]], H};
             if (e->gemm_p) {
                 ga.seqp = reinterpret_cast<__bf16 *>(e->seqP[l][slots[l]].p) + (long)t * H;
                 ga.seqp_ld = (long)T * H; ga.seqp_plane = (long)B * T * H; ga.seqp_pl = operand_planes(e->precision);
@@ -967,7 +981,7 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
         ProfScope ps(e, "k_gru_step", "gru_step", 2.0 * B * 3 * H * H * z, st);
         // (the same arithmetic as the single-stream path: batches of <= 16 streams split K over eight waves)
         if (B <= 16) hipLaunchKernelGGL(k_gru_step_multi8, dim3((H + 15) / 16, 1, z), dim3(512), 0, st, m);
-        else hipLaunchKernelGGL(k_gru_step_multi, dim3((H + 15) / 16, (B + 31) / 32, z), dim3(256), 0, st, m);
+        else hipLaunchKernelGGL(k_gru_step_multi, dim3((H + 15) / 16, (bmax + 31) / 32, z), dim3(256), 0, st, m);
     }
     HIPCHECK(e, hipGetLastError());
     return 0;
@@ -975,15 +989,17 @@ int stage_gru_round(se_engine *e, const int *slots, hipStream_t st) {
 
 int stage_gru_out(se_engine *e, int cur, hipStream_t st) {
     const int L = e->L, T = e->T, B = e->B, H = e->H, D = e->D;
+    const int Ba = e->Bact;
+    (void)B;
     int rc;
     if (e->dbg_skip & 2) {}
-    else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[e->NL - 1][cur].p, e->fcw_x.p, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc"))) return rc; }
-    else if ((rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, B * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
+    else if (e->gemm_p) { if ((rc = launch_gemm_p(e, e->seqP[e->NL - 1][cur].p, e->fcw_x.p, e->fcb.p, e->fc_out.p, D, Ba * T, D, H, e->act, st, "gru_fc"))) return rc; }
+    else if ((rc = launch_gemm(e, e->seqr[e->NL - 1][cur].p, H, e->fcw.p, H, e->fcb.p, e->fc_out.p, D, Ba * T, D, H, e->act, st, "gru_fc", e->fcw_x.p))) return rc;
     if (e->use_p) {  // decoder input in the plane layout
         const int PL = operand_planes(e->precision), C = e->Ch[L], C8 = (C + 7) / 8;
         ProfScope ps(e, "k_gln2_p", "gln", 0, st);
         Gln2PArgs g{e->fc_out.p, e->gnw.p, e->gnb.p, decin_p(e, cur), (long)C8 * PL * T * e->F[L], T, e->F[L], C, C8, e->eps_mode};
-        launch_k_gln2_p(PL, dim3(B), st, g);
+        launch_k_gln2_p(PL, dim3(Ba), st, g);
         HIPCHECK(e, hipGetLastError());
         return 0;
     }
@@ -1380,6 +1396,8 @@ static int reset_on_stream(se_engine *e, int batch, hipStream_t st) {
     if (rc) return rc;
     const int L = e->L, T = e->T, B = batch, H = e->H, D = e->D, F0 = e->F[0];
     e->B = B;
+    e->Bact = B;
+    for (int &v : e->bact_slot) v = B;
     // a few streams give the bottleneck GEMMs a few hundred rows: a 256 x 128 tile per workgroup leaves 12-36 workgroups
     // walking K = 2048 alone (124 us at B = 1); the skinny 32 x 32-tile fp32 kernel (K split over the waves) takes 24
     select_gemm_route(e);
@@ -1689,9 +1707,9 @@ static int step_dev(se_engine *e, const float *src, long strideB, long strideM, 
     int rc;
     cf2 *spec = reinterpret_cast<cf2 *>(e->spec[(e->slot + 1) % kRing].p);
     cf2 *ms = reinterpret_cast<cf2 *>(e->maskspec.p);
-    if ((rc = launch_stft(e, src, strideB, strideM, (int)M, off, Lsrc, e->B * (int)M, spec, T * F, F, 1, st))) return rc;
+    if ((rc = launch_stft(e, src, strideB, strideM, (int)M, off, Lsrc, e->Bact * (int)M, spec, T * F, F, 1, st))) return rc;
     if ((rc = forward_dev(e, spec, M * T * F, T * F, F, 1, ms, T * F, F, 1, st))) return rc;
-    return launch_istft(e, ms, T * F, F, 1, e->B, wav_out, wav_ld, st);
+    return launch_istft(e, ms, T * F, F, 1, e->Bact, wav_out, wav_ld, st);
 }
 
 int se_step(se_engine *e, const float *wav_in, float *wav_out, void *stream) {
@@ -1723,10 +1741,21 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
         e->pipeline = 0;
         piped = false;
     }
+    // launch batch of segment n: with non-increasing lengths the streams still running are a prefix of the batch (see se_engine::Bact)
+    static const bool compact_env = [] { const char *v = getenv("SE_RAGGED_COMPACT"); return !(v && v[0] == '0'); }();
+    const bool compact = compact_env && !e->ragged_nseg.empty() && e->use_p && e->gemm_p && e->variant == 0;
+    auto bact_of = [&](long n) {
+        if (!compact) return e->B;
+        int c = 0;
+        while (c < e->B && e->ragged_nseg[c] > n) c++;
+        return std::max(c, 1);
+    };
+    struct RestoreBact { se_engine *e; ~RestoreBact() { e->Bact = e->B; for (int &v : e->bact_slot) v = e->B; } } restore_bact{e};
     if (!piped) {
         for (long n = 0; n < Nseg; n++) {
             // segment n covers padded[n*P, n*P+K) with padded = [0]*P | [0]*lead | x | zeros
             const long off = n * P - P - lead;
+            e->Bact = bact_of(n);
             // yseg is [B][Nseg][K]: the iSTFT writes segment n of every stream with row stride Nseg*K
             if ((rc = step_dev(e, mixture, (long)e->M * length, length, off, length, e->yseg.p + n * K, Nseg * K, st))) return rc;
         }
@@ -1755,10 +1784,11 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 if (i < cn) {  // ---- encoder stream: STFT batch, features + encoder, GRU input projection of segment i ----
                     const int cur = slot_of(i), prev = slot_of(i - 1);
                     e->slot = cur;
+                    e->Bact = e->bact_slot[cur] = bact_of(c0 + i);
                     const cf2 *spec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * i);
                     if (i % kFftSub == 0) {
                         const long ns = std::min<long>(kFftSub, cn - i);
-                        if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, (c0 + i) * P - P - lead, length, e->B * (int)M,
+                        if ((rc = launch_stft(e, mixture, (long)e->M * length, length, (int)M, (c0 + i) * P - P - lead, length, e->Bact * (int)M,
                                               reinterpret_cast<cf2 *>(e->spec_all.p + spec_n * i), T * F, F, 1, sE, (int)ns, P, (long)(spec_n / 2)))) return rc;
                     }
                     if (i >= kRing) HIPCHECK(e, hipStreamWaitEvent(sE, e->ev_dec[cur], 0));  // slot cur was last read by the decoder of segment i - kRing
@@ -1776,6 +1806,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                     if ((rc = stage_gru_round(e, slots, sG))) return rc;
                     done = i - (NL - 1);
                 } else {
+                    e->Bact = e->bact_slot[slot_of(i)];
                     for (int l = 0; l < NL; l++)
                         if ((rc = stage_gru_layer(e, l, slot_of(i), sG, /*overlapped=*/true))) return rc;
                     done = i;
@@ -1783,6 +1814,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 if (done < 0 || done >= cn) continue;
                 // ---- decoder stream: fc + norm, decoder, mask, iSTFT batch of segment `done` ----
                 const int dcur = slot_of(done);
+                e->Bact = e->bact_slot[dcur];
                 HIPCHECK(e, hipEventRecord(e->ev_gru[dcur], sG));
                 HIPCHECK(e, hipStreamWaitEvent(sD, e->ev_gru[dcur], 0));
                 const cf2 *dspec = reinterpret_cast<const cf2 *>(e->spec_all.p + spec_n * done);
@@ -1791,7 +1823,7 @@ int se_realtime_process(se_engine *e, const float *mixture, int batch, int64_t l
                 if ((rc = run_decoder(e, dcur, dspec, M * T * F, F, 1, ms, T * F, F, 1, sD))) return rc;
                 if (done % kFftSub == kFftSub - 1 || done == cn - 1) {
                     const long i0 = done - done % kFftSub;
-                    if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i0), T * F, F, 1, e->B,
+                    if ((rc = launch_istft(e, reinterpret_cast<const cf2 *>(e->mask_all.p + mask_n * i0), T * F, F, 1, bact_of(c0 + i0) /* (the ring slot of segment i0 has been reused by now) */,
                                            e->yseg.p + (c0 + i0) * K, Nseg * K, sD, (int)(done - i0 + 1), (long)(mask_n / 2), K))) return rc;
                 }
                 HIPCHECK(e, hipEventRecord(e->ev_dec[dcur], sD));
@@ -1819,9 +1851,22 @@ int se_realtime_process_ragged(se_engine *e, const float *mixture, int batch, in
     static_assert(sizeof(long) == sizeof(int64_t), "per-stream lengths are passed to the kernels as long");
     HIPCHECK(e, hipMemcpyAsync(e->ragged_len.p, lengths_host, (size_t)batch * sizeof(int64_t), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     HIPCHECK(e, hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // the host array is borrowed for the call only
+    // segments stream b takes part in (the count it would have alone: utility.py:327-329, 360-368), for the prefix compaction; only when the
+    // lengths are non-increasing (the Python shim sorts the batch), otherwise every stream runs every segment as before
+    e->ragged_nseg.clear();
+    bool sorted = true;
+    for (int b = 1; b < batch; b++) sorted = sorted && lengths_host[b] <= lengths_host[b - 1];
+    if (sorted) {
+        const long K = e->K, P = K / 2, lead = flag ? 0 : P;
+        for (int b = 0; b < batch; b++) {
+            const long Lp = lengths_host[b] + lead, gap = K - (P + Lp % K) % K;
+            e->ragged_nseg.push_back((int)(2 * (Lp + gap + P) / K));
+        }
+    }
     e->ragged_on = true;
     rc = se_realtime_process(e, mixture, batch, max_length, flag, out, stream);
     e->ragged_on = false;
+    e->ragged_nseg.clear();
     return rc;
 }
 

@@ -253,8 +253,21 @@ class Engine:
             ln = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
             if len(ln) != B:
                 raise RuntimeError(f"{len(ln)} lengths for a batch of {B}")
-            arr = (C.c_int64 * B)(*ln)
-            self._check(self.lib.se_realtime_process_ragged(self._h, self._dev(mixture), B, L, arr, int(bool(flag)), self._dev(out, (B, L)), self._stream()))
+            # Prefix compaction: with non-increasing lengths the engine launches every segment for the streams still running
+            # only.  A fresh batch (flag=False) is therefore sorted by length here and un-sorted on the way out; a continuation keeps its
+            # slots (the carried state lives in them) and is compacted only if it happens to be sorted.
+            order = sorted(range(B), key=lambda i: -ln[i])
+            permute = not flag and order != list(range(B))
+            if permute:
+                idx = torch.tensor(order, dtype=torch.int64, device=mixture.device)
+                src, dst = mixture.index_select(0, idx).contiguous(), torch.empty_like(out)
+                ln_call = [ln[i] for i in order]
+            else:
+                src, dst, ln_call = mixture, out, ln
+            arr = (C.c_int64 * B)(*ln_call)
+            self._check(self.lib.se_realtime_process_ragged(self._h, self._dev(src), B, L, arr, int(bool(flag)), self._dev(dst, (B, L)), self._stream()))
+            if permute:
+                out.index_copy_(0, idx, dst)
             self.batch = B
             return out
         self._check(self.lib.se_realtime_process(self._h, self._dev(mixture), B, L, int(bool(flag)), self._dev(out, (B, L)), self._stream()))
