@@ -314,6 +314,11 @@ def timed_region(fn, steps, warmup, world, backend):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
+def train_ops_prof_off():
+    from speech_enhancement_mi_amd import train_ops
+    return train_ops.PROF is None  # the extra profiled step brackets every launch with events: eager
+
+
 def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_model=None):
     """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
     all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
@@ -331,7 +336,8 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
     model = model.cuda()
     model.use_hip_kernels(args.train_kernels == "hip")
     bucket = FlatBucket(list(model.parameters()))
-    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    graph_step = world == 1 and args.train_kernels == "hip" and args.data == "fixed" and getattr(args, "graph_step", False) and not args.no_merge
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, capturable=graph_step)
     U, L = args.utts, int(args.seconds * 16000)
     mix, clean = synth.synth_utterances(U, L, 3, seed=2000 + rank)
     mix, clean = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
@@ -371,7 +377,17 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
 
         prefetch()
 
+    gstep = {}
+
     def step():
+        if graph_step and train_ops_prof_off():
+            # one process, fixed shapes: the whole optimizer step is ONE captured HIP graph (training.GraphedTrainStep), replayed per step with
+            # the batch copied into its static inputs; the loss value stays on the device until it is read after the timed region
+            if "g" not in gstep:
+                from speech_enhancement_mi_amd.training import GraphedTrainStep
+                gstep["g"] = GraphedTrainStep(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss)
+            last["loss_t"] = gstep["g"](mix, clean)
+            return
         if args.data == "gen":
             torch.cuda.current_stream().wait_event(pending["ready"])
             mx, tgt = pending["batch"]
@@ -383,6 +399,9 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
+    if "loss_t" in last:
+        last["loss"] = float(last["loss_t"])
+        gstep["g"].check()
     assert np.isfinite(last["loss"])
     value = world * U * steps / dt
     roofline = None
@@ -411,7 +430,8 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
                   vs_baseline=None, dtype="f32", data="synthetic" if args.data != "gen" else "synthetic, generated on the GPU inside every step (rooms, RIRs, mix)",
                   config=dict(workload=f"{'CRN_ELU (CRN_ELU.py, the model train.py:16 trains)' if variant else 'TemporalCRN (CRN.py)'} 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
                                        f"loss = {args.train_loss}, accum {args.accum} ({'micro-batches share one forward/backward sweep, loss formed per micro-batch: same gradient' if not args.no_merge else 'micro-batches run one after the other'}), "
-                                       f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
+                                       f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4"
+                                       + ("; the whole step (forward, loss, backward, clip, Adam) replayed as ONE captured HIP graph, inputs copied into its static buffers every step" if graph_step else ""),
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
                               reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
                   roofline=roofline, cpu_baseline=None)
@@ -662,6 +682,8 @@ def parse_args(argv=None):
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--data", choices=["fixed", "gen"], default="fixed",
                     help="--mode train: fixed = one resident synthetic batch; gen = a fresh batch of simulated rooms per step from the GPU generator")
+    ap.add_argument("--graph-step", action="store_true", help="--mode train, 1 GPU: replay the whole step (forward + loss + backward + clip + Adam) as ONE captured HIP graph "
+                    "(training.GraphedTrainStep); measured SLOWER than the launch-by-launch step on ROCm 7.2 (299 vs 332 utt/s), hence off by default")
     ap.add_argument("--no-graph-loss", action="store_true", help="--mode train: launch the loss's ~150 device ops one by one instead of as a captured HIP graph")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
