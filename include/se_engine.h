@@ -182,6 +182,18 @@ double fsn_flops_per_frame(const fsn_engine *e);
  * (gscale is a 1-element device tensor: upstream gradient / B for the batch mean).  Enqueued on `stream`, no sync. */
 int se_loss_sisnr_fwd(const float *separated, const float *source, const int64_t *lens, int batch, int64_t length, float *per_utt,
                       double *stats, void *stream);
+/* STOI term of compute_loss (utility.stoi_loss, utility.py:821-916) as kernels, forward and backward w.r.t. the prediction.
+ * Tables (device memory, built by the caller once: losses._plan): rs_w [5][W] + rs_first [5] = the 16 kHz -> 10 kHz polyphase filter
+ * (Kaldi LinearResample, augment.py:478-545), hann_sym [256] = np.hanning(256) (utility.py:522), hann_per [256] = periodic Hann of the
+ * spectrogram, band_lo / band_hi [15] = third-octave band bin ranges (utility.thirdoct, utility.py:480-518).  ws = se_loss_stoi_ws_floats
+ * floats of scratch that carry the forward's intermediates to the backward.  D [batch] = STOI per utterance (0.99 for utterances too
+ * short to score, utility.py:877-880); gD = d loss / d D; dpred [batch][length]. */
+int64_t se_loss_stoi_ws_floats(int batch, int64_t length);
+int se_loss_stoi_fwd(const float *clean, const float *pred, const int64_t *lens, int batch, int64_t length, const float *rs_w, const int *rs_first, int W,
+                     const float *hann_sym, const float *hann_per, const int *band_lo, const int *band_hi, float *ws, float *D, void *stream);
+int se_loss_stoi_bwd(const float *gD, const int64_t *lens, int batch, int64_t length, const float *rs_w, const int *rs_first, int W, const float *hann_sym,
+                     const float *hann_per, const int *band_lo, const int *band_hi, float *ws, float *dpred, void *stream);
+const char *se_loss_stoi_last_error(void);
 int se_loss_sisnr_bwd(const float *separated, const float *source, const int64_t *lens, int batch, int64_t length, const double *stats,
                       const float *gscale, float *grad, void *stream);
 

@@ -22,6 +22,11 @@ def main():
     if multi:
         t_lo, t_hi = multi[len(multi) // 4][0], multi[-1][1]
         rows = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
+    elif len(sys.argv) > 3:  # other workloads: the window between the first and the last launch of a named kernel's last `frac` of launches
+        name, frac = sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
+        sel = [r for r in rows if name in r[2]]
+        t_lo, t_hi = sel[int(len(sel) * (1 - frac))][0], sel[-1][1]
+        rows = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
     out = open(sys.argv[2], "w")
 
     def base(k):

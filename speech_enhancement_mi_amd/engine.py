@@ -21,7 +21,7 @@ EXPORTS = [
     "se_realtime_process", "se_realtime_process_ragged", "se_stft", "se_istft", "se_forward", "se_read_tap", "se_read_tap_dev", "se_export_state",
     "se_import_state", "se_flops_per_frame", "se_frames_per_segment", "se_profile", "se_profile_read",
     "fsn_create", "fsn_destroy", "fsn_last_error", "fsn_load_param", "fsn_reset", "fsn_forward", "fsn_realtime_process",
-    "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd",
+    "fsn_read_tap", "fsn_flops_per_frame", "se_loss_sisnr_fwd", "se_loss_sisnr_bwd", "se_loss_stoi_ws_floats", "se_loss_stoi_fwd", "se_loss_stoi_bwd", "se_loss_stoi_last_error",
     "se_train_last_error", "se_train_conv_layout_query", "se_train_conv", "se_train_conv_wgrad", "se_train_gemm", "se_train_gemm_tn", "se_train_gru_step",
     "se_train_gru_bwd_gates", "se_train_gru_seq_fwd", "se_train_gru_seq_bwd", "se_train_gru_pseq_supported", "se_train_gru_pseq_scratch_floats", "se_train_gru_pseq_fwd", "se_train_gru_pseq_bwd",
     "se_sig_create", "se_sig_destroy", "se_sig_stft", "se_sig_istft", "se_train_ola_fwd", "se_train_ola_bwd", "se_train_feat", "se_train_mask_fwd",
@@ -102,6 +102,11 @@ def load_library():
     L.fsn_flops_per_frame.argtypes = [vp]
     L.fsn_flops_per_frame.restype = C.c_double
     L.se_loss_sisnr_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp]
+    L.se_loss_stoi_ws_floats.argtypes = [C.c_int, C.c_int64]
+    L.se_loss_stoi_ws_floats.restype = C.c_int64
+    L.se_loss_stoi_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.se_loss_stoi_bwd.argtypes = [vp, vp, C.c_int, C.c_int64, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.se_loss_stoi_last_error.restype = C.c_char_p
     L.se_loss_sisnr_bwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, vp]
     i32, i64 = C.c_int, C.c_int64
     L.se_train_last_error.restype = C.c_char_p

@@ -136,9 +136,15 @@ def _plan(device):
             obm[i, int(np.argmin(np.square(f - np.float32(lo_f[i])))):int(np.argmin(np.square(f - np.float32(hi_f[i]))))] = 1
         win512 = np.zeros(512, np.float32)
         win512[128:384] = (0.5 - 0.5 * np.cos(2 * np.pi * n / 256)).astype(np.float32)  # periodic Hann(256) centred in 512
+        lo_bin = [int(np.argmin(np.square(f - np.float32(lo_f[i])))) for i in range(15)]
+        hi_bin = [int(np.argmin(np.square(f - np.float32(hi_f[i])))) for i in range(15)]
         _PLAN[key] = dict(first=[int(v) for v in first], w=torch.from_numpy(w).to(device), stride=stride, phases=phases,
                           hann_sym=torch.from_numpy(np.hanning(256).astype(np.float32)).to(device),  # np.hanning(256), utility.py:522
-                          win512=torch.from_numpy(win512).to(device), obm=torch.from_numpy(obm).to(device))
+                          win512=torch.from_numpy(win512).to(device), obm=torch.from_numpy(obm).to(device),
+                          # tables of the kernel form (csrc/se_stoi.hip)
+                          first_dev=torch.tensor([int(v) for v in first], dtype=torch.int32, device=device),
+                          hann_per=torch.from_numpy(win512[128:384].copy()).to(device),
+                          band_lo=torch.tensor(lo_bin, dtype=torch.int32, device=device), band_hi=torch.tensor(hi_bin, dtype=torch.int32, device=device))
     return _PLAN[key]
 
 
@@ -246,6 +252,67 @@ def _stoi_d(y_true, y_pred, lens):
     return torch.where(Ls <= 512, torch.full_like(d, 0.99), d)
 
 
+STOI_KERNELS = True  # CUDA tensors: csrc/se_stoi.hip (6 + 4 launches); False: the batched torch restatement _stoi_d (~150 ops), the checker
+
+
+class _StoiHip(torch.autograd.Function):
+    """D[i] of utility.py:856-911 on the se_loss_stoi_* kernels; gradient to the prediction only."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred, lens):
+        from . import engine as _engine
+        lib = _engine.load_library()
+        P = _plan(y_pred.device)
+        B, L = y_pred.shape
+        yt, yp, ln = y_true.detach().contiguous().float(), y_pred.detach().contiguous().float(), lens.contiguous().to(torch.int64)
+        ws = torch.empty(int(lib.se_loss_stoi_ws_floats(B, L)), dtype=torch.float32, device=y_pred.device)
+        D = torch.empty(B, dtype=torch.float32, device=y_pred.device)
+        st = C.c_void_p(torch.cuda.current_stream(y_pred.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        tabs = (p(P["w"]), p(P["first_dev"]), int(P["w"].shape[1]), p(P["hann_sym"]), p(P["hann_per"]), p(P["band_lo"]), p(P["band_hi"]))
+        if lib.se_loss_stoi_fwd(p(yt), p(yp), p(ln), B, L, *tabs, p(ws), p(D), st):
+            raise RuntimeError(lib.se_loss_stoi_last_error().decode())
+        ctx.save_for_backward(ln, ws)
+        ctx.shape = (B, L)
+        ctx.dev = y_pred.device
+        return D
+
+    @staticmethod
+    def backward(ctx, gD):
+        from . import engine as _engine
+        lib = _engine.load_library()
+        ln, ws = ctx.saved_tensors
+        B, L = ctx.shape
+        P = _plan(ctx.dev)
+        g = gD.contiguous().float()
+        dpred = torch.empty(B, L, dtype=torch.float32, device=ctx.dev)
+        st = C.c_void_p(torch.cuda.current_stream(ctx.dev).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        tabs = (p(P["w"]), p(P["first_dev"]), int(P["w"].shape[1]), p(P["hann_sym"]), p(P["hann_per"]), p(P["band_lo"]), p(P["band_hi"]))
+        if lib.se_loss_stoi_bwd(p(g), p(ln), B, L, *tabs, p(ws), p(dpred), st):
+            raise RuntimeError(lib.se_loss_stoi_last_error().decode())
+        return None, dpred, None
+
+
+def _stoi_ws_views(ws, B, L):
+    """Named views into the kernels' workspace (the layout of csrc/se_stoi.hip:stoi_shape) - for tests and debugging."""
+    Lo = (L * 5 + 7) // 8
+    Fu = (Lo - 256) // 128 + 1
+    Tm = Fu + 2
+    off = [0]
+
+    def take(n):
+        at = off[0]
+        off[0] += (n + 3) & ~3
+        return at
+    o = {k: take(n) for k, n in (("t10", B * Lo), ("p10", B * Lo), ("n10", B), ("nk", B), ("order", B * Fu), ("rank", B * Fu), ("Ot", B * Tm * 15),
+                                 ("Op", B * Tm * 15), ("Sp", B * Tm * 257 * 2), ("dOp", B * Tm * 15), ("dfr", B * Tm * 256), ("dp10", B * Lo))}  # (+ cw, dw behind)
+    return dict(nk=ws[o["nk"]:o["nk"] + B].view(torch.int32), n10=ws[o["n10"]:o["n10"] + B].view(torch.int32),
+                Ot=ws[o["Ot"]:o["Ot"] + B * Tm * 15].view(B, Tm, 15), Op=ws[o["Op"]:o["Op"] + B * Tm * 15].view(B, Tm, 15),
+                dOp=ws[o["dOp"]:o["dOp"] + B * Tm * 15].view(B, Tm, 15), dp10=ws[o["dp10"]:o["dp10"] + B * Lo].view(B, Lo),
+                p10=ws[o["p10"]:o["p10"] + B * Lo].view(B, Lo), t10=ws[o["t10"]:o["t10"] + B * Lo].view(B, Lo))
+
+
 def stoi_loss(y_true_batch, y_pred_batch, lens, reduction="mean"):
     """utility.stoi_loss: -STOI of the enhanced waveform against the clean one (batch mean, or per utterance for
     reduction != "mean").  Stays on the device of `y_pred_batch`; gradients flow to `y_pred_batch`."""
@@ -253,7 +320,10 @@ def stoi_loss(y_true_batch, y_pred_batch, lens, reduction="mean"):
     y_true_batch = torch.squeeze(y_true_batch, dim=-1) if y_true_batch.dim() == 3 else y_true_batch
     B, L = y_pred_batch.shape
     lens_t = _lens_tensor(lens, B, L, y_pred_batch.device)
-    D = _stoi_d(y_true_batch.to(y_pred_batch.device), y_pred_batch, lens_t)
+    if STOI_KERNELS and y_pred_batch.is_cuda and (L * 5 + 7) // 8 >= 256:
+        D = _StoiHip.apply(y_true_batch.to(y_pred_batch.device), y_pred_batch, lens_t)
+    else:
+        D = _stoi_d(y_true_batch.to(y_pred_batch.device), y_pred_batch, lens_t)
     return -D.mean() if reduction == "mean" else -D
 
 

@@ -533,6 +533,62 @@ def test_graphed_train_step_equals_eager_train_step():
     assert _rel(finals[1], finals[0]) < 1e-4
 
 
+def test_stoi_kernels_equal_the_torch_restatement():
+    """csrc/se_stoi.hip (6 launches forward, 4 backward) against losses._stoi_d (the batched torch restatement that is pinned to the genuine
+    reference by loss_golden.npz): per-utterance STOI and the gradient w.r.t. the prediction, full-length and ragged utterances incl. one
+    with fewer than 30 spectrogram frames (utility.py:882-885) and one too short to score (0.99, utility.py:877-880).
+
+    Values agree to fp32 spectra (a direct DFT here, rocFFT there).  The GRADIENT of STOI is not continuous - min(alpha Y, (1 + c) X) clips
+    10-28 % of the envelope entries and an entry within rounding of the clip edge takes the other branch - so two correct implementations
+    differ by ~1e-3 in norm; the correlation stage's backward is therefore also checked exactly, against float64 autograd on the kernels'
+    OWN envelopes (2.5e-8), and the linear stages behind it (envelope -> frames -> 10 kHz -> 16 kHz) by the overall agreement."""
+    from speech_enhancement_mi_amd import losses
+    L = 24000
+    mix, clean = synth.synth_utterances(6, L, 3, seed=41)
+    src = torch.from_numpy(clean).cuda()
+    noise = torch.from_numpy(mix[:, 0].copy()).cuda()
+    lens = torch.tensor([24000, 17001, 9000, 20000, 5500, 700], dtype=torch.int64, device="cuda")
+    res = []
+    for kern in (False, True):
+        losses.STOI_KERNELS = kern
+        try:
+            pred = (0.55 * src + 0.45 * noise).requires_grad_()
+            per = losses.stoi_loss(src, pred, lens, reduction="none")          # -D per utterance
+            (per * torch.arange(1, 7, device="cuda")).sum().backward()        # distinct upstream gradients
+            res.append((per.detach().cpu().double().numpy(), pred.grad.detach().cpu().double()))
+        finally:
+            losses.STOI_KERNELS = True
+    assert np.abs(res[0][0] - res[1][0]).max() < 5e-5, (res[0][0], res[1][0])
+    assert abs(res[1][0][5] + 0.99) < 1e-6
+    for b in range(6):
+        ref, got = res[0][1][b], res[1][1][b]
+        assert float((got - ref).norm() / (ref.norm() + 1e-30)) < 5e-3 or float(ref.norm()) == 0.0, b
+        if int(lens[b]) < L:
+            assert float(got[int(lens[b]):].abs().max()) == 0.0
+    # the correlation stage's backward, exactly: float64 autograd on the envelopes the kernels computed
+    pred = (0.55 * src + 0.45 * noise).requires_grad_()
+    Dk = losses._StoiHip.apply(src, pred, lens)
+    fn = Dk.grad_fn
+    (-Dk).sum().backward(retain_graph=True)
+    v = losses._stoi_ws_views(fn.saved_tensors[1], 6, L)
+    nk = v["nk"].cpu().numpy()
+    Ot, Op = v["Ot"].cpu().double(), v["Op"].cpu().double().requires_grad_()
+    tot = 0
+    for b in range(5):
+        T = int(nk[b]) + 2
+        X, Y = (Ot[b, :T].unfold(0, 30, 1), Op[b, :T].unfold(0, 30, 1)) if T >= 30 else (Ot[b, :T].T, Op[b, :T].T)
+        alpha = X.norm(dim=-1, keepdim=True) / (Y.norm(dim=-1, keepdim=True) + losses.SMALL)
+        yc = torch.minimum(Y * alpha, X + X * 5.62341325)
+        xn = X - X.mean(-1, keepdim=True)
+        xn = xn / (xn.norm(dim=-1, keepdim=True) + losses.SMALL)
+        yn = yc - yc.mean(-1, keepdim=True)
+        yn = yn / (yn.norm(dim=-1, keepdim=True) + losses.SMALL)
+        tot = tot - (xn * yn).sum() / (15.0 * (T - 29) if T >= 30 else 15.0)
+    tot.backward()
+    got, ref = v["dOp"].cpu().double()[:5], Op.grad[:5]
+    assert float((got - ref).norm() / ref.norm()) < 1e-6
+
+
 # ---- config 5 in its named dtype at size; the bounded regression guard of the round-2 fault -------------------------------------
 def test_student_batch1024_fp16_named_dtype():
     """BASELINE configs[4] names fp16: precision = 1 (fp16 MFMA operands, fp32 accumulation and storage of the recurrence / norms) at
