@@ -4,8 +4,9 @@
 * `cal_si_snr` restates utility.py:207-223.  On GPU tensors it runs as ONE fused HIP kernel pair (csrc/se_loss.hip through the
   C ABI `se_loss_sisnr_fwd/bwd`): per-utterance moment reductions in the forward, a closed-form elementwise backward - no
   Python loop over the batch, no host hop.  On CPU tensors (unit tests, CPU training) the same formula runs in torch.
-* `stoi_loss` restates utility.py:821-916 (+ thirdoct 480-518, removeSilentFrames 521-571) as batched, differentiable torch
-  tensor code that stays on the tensors' device.  The reference moves every utterance to the CPU and loops in Python
+* `stoi_loss` on CUDA tensors runs on the `se_loss_stoi_*` kernels (csrc/se_stoi.hip: 7 launches forward, 4 backward; `_StoiHip`).
+  `_stoi_d` restates utility.py:821-916 (+ thirdoct 480-518, removeSilentFrames 521-571) as batched, differentiable torch
+  tensor code that stays on the tensors' device: the CPU path and the checker the kernels are tested against (STOI_KERNELS = False).  The reference moves every utterance to the CPU and loops in Python
   (`y_pred_batch.cpu()`, utility.py:845-880); here the whole batch is processed at once with validity masks - the
   data-dependent lengths (silent-frame removal) never come back to the host, so there is no synchronisation in the loss.
   The two torchaudio==0.7.2 transforms it calls are absent from the reference tree and this image and are restated:
