@@ -395,7 +395,7 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
         else:
             mx, tgt = mix, clean
         last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge,
-                                  graph_loss=False if getattr(args, "no_graph_loss", False) else None)
+                                  graph_loss=bool(getattr(args, "graph_loss", False)))
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
@@ -684,7 +684,7 @@ def parse_args(argv=None):
                     help="--mode train: fixed = one resident synthetic batch; gen = a fresh batch of simulated rooms per step from the GPU generator")
     ap.add_argument("--graph-step", action="store_true", help="--mode train, 1 GPU: replay the whole step (forward + loss + backward + clip + Adam) as ONE captured HIP graph "
                     "(training.GraphedTrainStep); measured SLOWER than the launch-by-launch step on ROCm 7.2 (299 vs 332 utt/s), hence off by default")
-    ap.add_argument("--no-graph-loss", action="store_true", help="--mode train: launch the loss's ~150 device ops one by one instead of as a captured HIP graph")
+    ap.add_argument("--graph-loss", action="store_true", help="--mode train: replay the loss as a captured HIP graph per micro-batch (paid only while STOI was ~150 torch ops)")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")

@@ -306,10 +306,9 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     the same gradient up to fp32 summation order (tests/test_gpu_round3.py::test_merged_microbatches_give_the_accumulated_gradient).
     merge=False runs the micro-batches one after the other like the reference loop.
 
-    graph_loss (default: on with the hand-written kernels): the full loss (STOI + SI-SNR, ~150 small launches) runs as a captured HIP
-    graph per (micro-batch shape), forward and backward (losses.compute_loss_graphed); values and gradient unchanged.  A new shape costs
-    one capture (~1 s) and the 16 most recent shapes are kept: a trainer whose padded length changes every step should bucket its
-    lengths or pass graph_loss=False."""
+    graph_loss (default off): run the loss as a captured HIP graph per micro-batch shape (losses.compute_loss_graphed).  It paid when the
+    STOI term was ~150 torch ops per micro-batch (+12 % on CRN_ELU's step); with the se_loss_stoi_* kernels the loss is a dozen launches
+    and the eager form is as fast (383 vs 380 utt/s), without a capture per new shape."""
     bucket.zero()
     total = 0.0
     if merge is None:
@@ -318,7 +317,7 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     lens = [None] * len(srcs) if length is None else list(length.chunk(accum))
 
     if graph_loss is None:
-        graph_loss = model._hip
+        graph_loss = False
 
     def loss_of(pred, src, ln, slot=0):
         if loss == "full":
