@@ -197,47 +197,61 @@ __global__ __launch_bounds__(256) void k_stoi_env(const float *sig10, long Lo, c
     }
 }
 
-// The clipped, normalised correlation of one window: X = clean envelope, Y = predicted envelope, n entries of which the first `valid`
-// count for the mean (`cnt`); returns corr and (optionally) d corr / d Y
-__device__ inline double stoi_window(const double *X, const double *Y, int n, double cnt, double *dY) {
+// The clipped, normalised correlation of one window of n <= 30 entries (X = clean envelope, Y = predicted envelope, fp32 values, double
+// arithmetic like the restatement's .double()): returns corr and writes d corr / d Y_i to dy[i] (fp32).  Five passes over the entries
+// kept in registers; nothing but scalars is carried between them (a first form with double arrays for yc / d yc spilled to scratch:
+// 138 us per launch).  `cnt` = entries that count for the means (= n here).
+__device__ inline double stoi_window(const float (&X)[kSeg], const float (&Y)[kSeg], int n, double cnt, float *dy) {
     double nx2 = 0, ny2 = 0;
-    for (int i = 0; i < n; i++) { nx2 += X[i] * X[i]; ny2 += Y[i] * Y[i]; }
+#pragma unroll
+    for (int i = 0; i < kSeg; i++)
+        if (i < n) { nx2 += (double)X[i] * X[i]; ny2 += (double)Y[i] * Y[i]; }
     const double nX = sqrt(nx2), nY = sqrt(ny2), a = nX / (nY + kSmall);
-    double yc[kSeg], mx = 0, my = 0;
-    bool takeu[kSeg];
-    for (int i = 0; i < n; i++) {
-        const double u = Y[i] * a, v = X[i] + X[i] * kClip;
-        takeu[i] = u <= v;
-        yc[i] = takeu[i] ? u : v;
-        mx += X[i]; my += yc[i];
-    }
+    auto clipped = [&](int i, bool &takeu) {
+        const double u = (double)Y[i] * a, v = (double)X[i] + (double)X[i] * kClip;
+        takeu = u <= v;
+        return takeu ? u : v;
+    };
+    double mx = 0, my = 0;
+#pragma unroll
+    for (int i = 0; i < kSeg; i++)
+        if (i < n) { bool tu; mx += X[i]; my += clipped(i, tu); }
     mx /= cnt; my /= cnt;
-    double xc2 = 0, yc2 = 0;
-    for (int i = 0; i < n; i++) { const double xc = X[i] - mx, yy = yc[i] - my; xc2 += xc * xc; yc2 += yy * yy; }
+    double xc2 = 0, yc2 = 0, xy = 0;
+#pragma unroll
+    for (int i = 0; i < kSeg; i++)
+        if (i < n) { bool tu; const double xc = X[i] - mx, yy = clipped(i, tu) - my; xc2 += xc * xc; yc2 += yy * yy; xy += xc * yy; }
     const double nxc = sqrt(xc2), nyc = sqrt(yc2);
-    double corr = 0;
-    for (int i = 0; i < n; i++) corr += ((X[i] - mx) / (nxc + kSmall)) * ((yc[i] - my) / (nyc + kSmall));
-    if (dY) {
-        // g_i = d corr / d yn_i = xn_i;  yn = ycm / (nyc + eps)
-        double gdot = 0;
-        for (int i = 0; i < n; i++) gdot += ((X[i] - mx) / (nxc + kSmall)) * (yc[i] - my);
-        double dyc[kSeg], mean_d = 0;
-        for (int i = 0; i < n; i++) {
-            const double g = (X[i] - mx) / (nxc + kSmall);
-            double d = g / (nyc + kSmall);
-            if (nyc > 0) d -= gdot * (yc[i] - my) / (nyc * (nyc + kSmall) * (nyc + kSmall));
-            dyc[i] = d;
-            mean_d += d;
-        }
+    const double ix = 1.0 / (nxc + kSmall), iy = 1.0 / (nyc + kSmall);
+    const double corr = xy * ix * iy;
+    if (dy) {
+        // g_i = d corr / d yn_i = xn_i,  yn = ycm / (nyc + eps):  d_i = g_i iy - (sum_j g_j ycm_j) ycm_i / (nyc (nyc + eps)^2), then centring
+        const double gdot = xy * ix, k2 = nyc > 0 ? gdot * iy * iy / nyc : 0.0;
+        double mean_d = 0, du_dot = 0;
+#pragma unroll
+        for (int i = 0; i < kSeg; i++)
+            if (i < n) { bool tu; const double yy = clipped(i, tu) - my; mean_d += (X[i] - mx) * ix * iy - k2 * yy; }
         mean_d /= cnt;
-        double du_dot = 0;
-        for (int i = 0; i < n; i++) {
-            dyc[i] -= mean_d;                  // centring
-            dyc[i] = takeu[i] ? dyc[i] : 0.0;  // min(u, v): the gradient goes to u where u is the smaller
-            du_dot += dyc[i] * Y[i];
-        }
+#pragma unroll
+        for (int i = 0; i < kSeg; i++)
+            if (i < n) {
+                bool tu;
+                const double yy = clipped(i, tu) - my;
+                const double d = (X[i] - mx) * ix * iy - k2 * yy - mean_d;
+                if (tu) du_dot += d * Y[i];  // min(u, v): the gradient goes to u where u is the smaller
+            }
         const double da = nY > 0 ? -nX / ((nY + kSmall) * (nY + kSmall)) / nY : 0.0;  // d a / d Y_k = da * Y_k
-        for (int i = 0; i < n; i++) dY[i] = a * dyc[i] + du_dot * da * Y[i];
+#pragma unroll
+        for (int i = 0; i < kSeg; i++) {
+            float out = 0.0f;
+            if (i < n) {
+                bool tu;
+                const double yy = clipped(i, tu) - my;
+                const double d = tu ? (X[i] - mx) * ix * iy - k2 * yy - mean_d : 0.0;
+                out = (float)(a * d + du_dot * da * Y[i]);
+            }
+            dy[i] = out;
+        }
     }
     return corr;
 }
@@ -272,10 +286,14 @@ __global__ __launch_bounds__(256) void k_stoi_corr_win(const float *Ot, const fl
     float *dy = dw + (((long)b * kBands + band) * Mmax + m) * kSeg;
     if (m < Mi && n > 0) {
         const float *ot = Ot + (long)b * Tm * kBands, *op = Op + (long)b * Tm * kBands;
-        double X[kSeg], Y[kSeg], dY[kSeg];
-        for (int i = 0; i < n; i++) { X[i] = ot[(long)(m + i) * kBands + band]; Y[i] = op[(long)(m + i) * kBands + band]; }
-        corr = stoi_window(X, Y, n, (double)max(n, 1), dY);
-        for (int i = 0; i < kSeg; i++) dy[i] = i < n ? (float)dY[i] : 0.0f;
+        float X[kSeg], Y[kSeg];
+#pragma unroll
+        for (int i = 0; i < kSeg; i++) {
+            const long r = (long)min(m + i, Tm - 1) * kBands + band;
+            X[i] = i < n ? ot[r] : 0.0f;
+            Y[i] = i < n ? op[r] : 0.0f;
+        }
+        corr = stoi_window(X, Y, n, (double)max(n, 1), dy);
     } else {
         for (int i = 0; i < kSeg; i++) dy[i] = 0.0f;
     }
