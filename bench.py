@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  One leg uses the caller's stream + three
-# stage streams (CRN), or + two side streams (FullSubNet / training layer wavefront) + the loss graph's stream: with earlier legs' streams in
+# stage streams (CRN), or + two side streams (FullSubNet / training layer wavefront): with earlier legs' streams in
 # the round-robin, two of a leg's own streams can land on one queue and serialise (training leg 289 -> 306 utt/s, student +1 %, CRN_ELU
 # +2 % with 8 queues; the headline itself is unchanged).  Read by the runtime at initialisation, inherited by the rank processes.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -314,11 +314,6 @@ def timed_region(fn, steps, warmup, world, backend):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
-def train_ops_prof_off():
-    from speech_enhancement_mi_amd import train_ops
-    return train_ops.PROF is None  # the extra profiled step brackets every launch with events: eager
-
-
 def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_model=None):
     """BASELINE configs[3]: TemporalCRN data-parallel training, utterances sharded across ranks, ONE flat fp32 gradient
     all-reduce (24.5 MB) per optimizer step.  A step = forward + backward over `--utts` 3 s utterances per GPU (two
@@ -336,8 +331,7 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
     model = model.cuda()
     model.use_hip_kernels(args.train_kernels == "hip")
     bucket = FlatBucket(list(model.parameters()))
-    graph_step = world == 1 and args.train_kernels == "hip" and args.data == "fixed" and getattr(args, "graph_step", False) and not args.no_merge
-    opt = torch.optim.Adam(model.parameters(), lr=3e-4, capturable=graph_step)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
     U, L = args.utts, int(args.seconds * 16000)
     mix, clean = synth.synth_utterances(U, L, 3, seed=2000 + rank)
     mix, clean = torch.from_numpy(mix).cuda(), torch.from_numpy(clean).cuda()
@@ -377,31 +371,17 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
 
         prefetch()
 
-    gstep = {}
-
     def step():
-        if graph_step and train_ops_prof_off():
-            # one process, fixed shapes: the whole optimizer step is ONE captured HIP graph (training.GraphedTrainStep), replayed per step with
-            # the batch copied into its static inputs; the loss value stays on the device until it is read after the timed region
-            if "g" not in gstep:
-                from speech_enhancement_mi_amd.training import GraphedTrainStep
-                gstep["g"] = GraphedTrainStep(model, bucket, opt, mix, clean, accum=args.accum, loss=args.train_loss)
-            last["loss_t"] = gstep["g"](mix, clean)
-            return
         if args.data == "gen":
             torch.cuda.current_stream().wait_event(pending["ready"])
             mx, tgt = pending["batch"]
             prefetch()
         else:
             mx, tgt = mix, clean
-        last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge,
-                                  graph_loss=bool(getattr(args, "graph_loss", False)))
+        last["loss"] = train_step(model, bucket, opt, mx, tgt, accum=args.accum, loss=args.train_loss, merge=not args.no_merge)
 
     progress(f"train: {warmup} + {steps} steps, kernels = {args.train_kernels}, loss = {args.train_loss}")
     dt = timed_region(step, steps, warmup, world, backend)
-    if "loss_t" in last:
-        last["loss"] = float(last["loss_t"])
-        gstep["g"].check()
     assert np.isfinite(last["loss"])
     value = world * U * steps / dt
     roofline = None
@@ -430,8 +410,7 @@ def train_measure(args, rank, local_rank, world, backend, steps, warmup, train_m
                   vs_baseline=None, dtype="f32", data="synthetic" if args.data != "gen" else "synthetic, generated on the GPU inside every step (rooms, RIRs, mix)",
                   config=dict(workload=f"{'CRN_ELU (CRN_ELU.py, the model train.py:16 trains)' if variant else 'TemporalCRN (CRN.py)'} 400-pt training step: {U} utterances/GPU x {args.seconds:g} s, forward/backward kernels = {args.train_kernels}, "
                                        f"loss = {args.train_loss}, accum {args.accum} ({'micro-batches share one forward/backward sweep, loss formed per micro-batch: same gradient' if not args.no_merge else 'micro-batches run one after the other'}), "
-                                       f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4"
-                                       + ("; the whole step (forward, loss, backward, clip, Adam) replayed as ONE captured HIP graph, inputs copied into its static buffers every step" if graph_step else ""),
+                                       f"flat 24.5 MB fp32 gradient all-reduce, clip 5, Adam 3e-4",
                               utterances_per_gpu=U, parallelism=f"dp{world}", grad_bucket_bytes=int(bucket.flat.numel() * 4),
                               reference_note="the reference logged 1.09 utterances/s at batch 1 on an unknown GPU (BASELINE.md 1): not this metric's baseline"),
                   roofline=roofline, cpu_baseline=None)
@@ -682,9 +661,6 @@ def parse_args(argv=None):
     ap.add_argument("--accum", type=int, default=2, help="--mode train: micro-batches per optimizer step (config.yaml:99 uses 2)")
     ap.add_argument("--data", choices=["fixed", "gen"], default="fixed",
                     help="--mode train: fixed = one resident synthetic batch; gen = a fresh batch of simulated rooms per step from the GPU generator")
-    ap.add_argument("--graph-step", action="store_true", help="--mode train, 1 GPU: replay the whole step (forward + loss + backward + clip + Adam) as ONE captured HIP graph "
-                    "(training.GraphedTrainStep); measured SLOWER than the launch-by-launch step on ROCm 7.2 (299 vs 332 utt/s), hence off by default")
-    ap.add_argument("--graph-loss", action="store_true", help="--mode train: replay the loss as a captured HIP graph per micro-batch (paid only while STOI was ~150 torch ops)")
     ap.add_argument("--no-merge", action="store_true", help="--mode train: run the accumulation micro-batches one after the other (default: one shared sweep, same gradient)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only: skip the FullSubNet / student / CRN_ELU / training legs")

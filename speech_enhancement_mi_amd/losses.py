@@ -337,31 +337,3 @@ def compute_loss(source, pred_source, length):
     bad = torch.isnan(loss)
     zero = torch.zeros_like(loss)  # no gradient, like the reference's fill_(0.0)
     return torch.where(bad, zero, loss), torch.where(bad, zero, stoi), torch.where(bad, zero, sisnr)
-
-
-# ---- the loss as ONE HIP-graph launch (training step) ---------------------------------------------------------------------------
-# compute_loss is ~150 small device ops (resampler phases, silent-frame sort / gather, 512-pt spectrogram, octave bands, the 30-frame
-# clipped correlation, SI-SNR) on [micro-batch, 48 000] samples: 4.6 ms of host launch time for well under 1 ms of device work, inside a
-# 23-ms training step (profiles/r03_host_enqueue.txt).  Every shape in it is a function of (B, L) alone and nothing reads back to the
-# host, so forward and backward are captured once per (B, L, device) and replayed (torch.cuda.make_graphed_callables: two hipGraphs).
-_GRAPHED = {}   # insertion-ordered; at most _GRAPHED_MAX captured shapes are kept (a trainer with random crop lengths sees many)
-_GRAPHED_MAX = 16
-
-
-def compute_loss_graphed(source, pred_source, length, slot=0):
-    """compute_loss for CUDA tensors with a fixed (B, L): same values and the same gradient w.r.t. pred_source, two graph launches.
-    A captured graph owns ONE set of static buffers (inputs, saved activations, outputs): calls whose backward has not run yet must not
-    share it, so the caller numbers the calls of one autograd pass (`slot` = micro-batch index)."""
-    key = (tuple(pred_source.shape), tuple(source.shape), str(pred_source.device), pred_source.requires_grad, slot)
-    fn = _GRAPHED.get(key)
-    if fn is None:
-        def body(src, pred, ln):
-            return torch.stack(compute_loss(src, pred, ln))
-        sample = (source.detach().clone(), pred_source.detach().clone().requires_grad_(pred_source.requires_grad), length.detach().clone())
-        while len(_GRAPHED) >= _GRAPHED_MAX:
-            _GRAPHED.pop(next(iter(_GRAPHED)))  # oldest capture (its graphs and static buffers are freed with it)
-        fn = _GRAPHED[key] = torch.cuda.make_graphed_callables(body, sample)
-    else:
-        _GRAPHED[key] = _GRAPHED.pop(key)  # most recently used last
-    out = fn(source, pred_source, length).clone()  # the static output buffer is rewritten by the next replay
-    return out[0], out[1], out[2]

@@ -212,90 +212,7 @@ class FlatBucket:
         return norm
 
 
-class GraphedTrainStep:
-    """The whole optimizer step of train_step - forward, loss, backward, clip, Adam - captured ONCE as a HIP graph and replayed.
-
-    MEASURED SLOWER than train_step on ROCm 7.2 / MI355X (CRN.py 299 vs 332 utt/s, CRN_ELU.py 233 vs 248: `bench.py --mode train
-    --graph-step`), so nothing uses it by default: the step's ~250 dependent launches leave ~20 % of its 24 ms as launch-to-launch gaps
-    although the host enqueues ahead of the GPU, but replaying them as graph nodes (with the layer wavefront's cross-stream edges) costs
-    more than the gaps.  Kept as a correct, tested alternative (tests/test_gpu_round3.py::test_graphed_train_step_equals_eager_train_step)
-    for runtimes whose graph launch is cheaper.  Every shape is fixed by (utterances, length), nothing in the step reads back to the host (the clip is
-    a clamp of a device scalar here; `pseq_check` and the loss value are read after the replay), the side streams of the recurrence's
-    layer wavefront fork from and join the capturing stream, so the capture is a plain torch.cuda.graph().  Single process only: with
-    world_size > 1 the all-reduce stays outside a graph - use train_step.
-
-    optimizer: torch.optim.Adam(..., capturable=True).  Call: loss = step(mixture, source[, length]) -> device scalar (read it when you
-    need it); the gradient clip, micro-batch merge and loss are those of train_step(accum=..., loss=...)."""
-
-    def __init__(self, model, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "full", warmup: int = 3):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("GraphedTrainStep is single-process; use train_step under data parallelism")
-        if not model._hip:
-            raise RuntimeError("GraphedTrainStep needs the hand-written kernel path (model.use_hip_kernels(True))")
-        self.model, self.bucket, self.opt, self.accum, self.loss_kind = model, bucket, optimizer, accum, loss
-        self.mix, self.src = mixture.detach().clone(), source.detach().clone()
-        self.len = None if length is None else length.detach().clone().to(torch.int64)
-        # warm-up and capture run real steps: parameters and optimizer state are put back afterwards (in place: the graph holds their addresses)
-        params = [p for g in optimizer.param_groups for p in g["params"]]
-        snap_p = [p.detach().clone() for p in params]
-        snap_s = {id(p): {k: v.detach().clone() for k, v in optimizer.state[p].items() if torch.is_tensor(v)} for p in params if p in optimizer.state}
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):  # eager warm-up on a side stream: lazy allocations, kernel attributes, FFT plans, Adam state
-            for _ in range(warmup):
-                self._body()
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.value = self._body()
-        with torch.no_grad():
-            for p, q in zip(params, snap_p):
-                p.copy_(q)
-                for k, v in optimizer.state[p].items():
-                    if torch.is_tensor(v):
-                        old = snap_s.get(id(p), {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
-        torch.cuda.synchronize()
-
-    def _body(self):
-        from .losses import compute_loss
-        self.bucket.zero()
-        pred = self.model.realtime_process_train(self.mix)
-        srcs = self.src.chunk(self.accum)
-        lens = [None] * len(srcs) if self.len is None else list(self.len.chunk(self.accum))
-        val = None
-        for p_i, src, ln in zip(pred.chunk(self.accum), srcs, lens):
-            if self.loss_kind == "full":
-                ll = ln if ln is not None else torch.full((p_i.shape[0],), p_i.shape[-1], dtype=torch.int64, device=p_i.device)
-                v = compute_loss(src, p_i, ll)[0] / self.accum
-            else:
-                v = si_snr_loss(p_i, src, ln) / self.accum
-            val = v if val is None else val + v
-        val.backward()
-        norm = self.bucket.flat.norm()  # clip_grad_norm_(5): the same scale as FlatBucket.clip_, as a device scalar
-        self.bucket.flat.mul_(torch.clamp(5.0 / (norm + 1e-6), max=1.0))
-        self.opt.step()
-        return val.detach()
-
-    def __call__(self, mixture, source, length=None):
-        self.mix.copy_(mixture)
-        self.src.copy_(source)
-        if self.len is not None and length is not None:
-            self.len.copy_(length)
-        self.graph.replay()
-        return self.value
-
-    def check(self):
-        """Surfaces a persistent GRU launch that gave up its bounded spin (synchronises); call it every so often."""
-        from . import train_ops
-        train_ops.pseq_check()
-
-
-def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr", merge=None,
-               graph_loss=None):
+def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, source, length=None, accum: int = 1, loss: str = "sisnr", merge=None):
     """One optimizer step of the reference trainer (train.py:195-204) under data parallelism: `accum` micro-batches of local
     utterances, one flat all-reduce, clip 5, Adam.  loss = "full": 0.7 * stoi_loss + 0.3 * (-SI-SNR) (compute_loss,
     CRN.py:609-611); "sisnr": the SI-SNR term alone.
@@ -304,11 +221,7 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     is per utterance, so the `accum` micro-batches can share ONE forward / backward sweep (half the dependent GRU steps) while
     the loss is still formed per micro-batch, sum_i loss(micro-batch i) / accum - the same function of the parameters, hence
     the same gradient up to fp32 summation order (tests/test_gpu_round3.py::test_merged_microbatches_give_the_accumulated_gradient).
-    merge=False runs the micro-batches one after the other like the reference loop.
-
-    graph_loss (default off): run the loss as a captured HIP graph per micro-batch shape (losses.compute_loss_graphed).  It paid when the
-    STOI term was ~150 torch ops per micro-batch (+12 % on CRN_ELU's step); with the se_loss_stoi_* kernels the loss is a dozen launches
-    and the eager form is as fast (383 vs 380 utt/s), without a capture per new shape."""
+    merge=False runs the micro-batches one after the other like the reference loop."""
     bucket.zero()
     total = 0.0
     if merge is None:
@@ -316,15 +229,9 @@ def train_step(model: TrainableCRN, bucket: FlatBucket, optimizer, mixture, sour
     srcs = source.chunk(accum)
     lens = [None] * len(srcs) if length is None else list(length.chunk(accum))
 
-    if graph_loss is None:
-        graph_loss = False
-
     def loss_of(pred, src, ln, slot=0):
         if loss == "full":
             ll = ln if ln is not None else torch.full((pred.shape[0],), pred.shape[-1], dtype=torch.int64, device=pred.device)
-            if graph_loss and pred.is_cuda:
-                from .losses import compute_loss_graphed
-                return compute_loss_graphed(src.contiguous(), pred.contiguous(), ll.to(torch.int64), slot=slot)[0] / accum
             return model.compute_loss(src, pred, ll)[0] / accum
         return si_snr_loss(pred, src, ln) / accum
 
