@@ -139,7 +139,7 @@ int se_profile(se_engine *e, int enable);
 int se_profile_read(se_engine *e, int index, char *kernel, char *label, int cap, double *ms_total,
                     int64_t *launches, double *flops_per_launch);
 
-int se_abi_version(void);  /* 4 since round 3 (fsn_config.precision, se_sig_*, fused training stages) */
+int se_abi_version(void);  /* 4 since round 3 (fsn_config.precision, se_sig_*, fused training stages, se_realtime_process_ragged, se_read_tap_dev, se_loss_stoi_*) */
 /* sizeof(se_config) / sizeof(fsn_config) as this library was built: a binding checks its own struct mirror against these
  * before the first se_create (a short struct would leave `precision` reading whatever follows it). */
 int se_config_size(void);
